@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's ``GaussianProcess`` for the predict path.
+
+Same class name, method names, argument meaning and return shapes as
+gp_emulator/GaussianProcess.py, so scripts written against the reference
+(tests/benchmark.py, tests/test_perband_emulator.py) keep working:
+
+  predict(testing, do_unc=True, is_gpu=False, precision=np.float64, threshold=2e5)  :327-341
+  gpu_predict(testing, precision, threshold)                                          :273-323
+  get_gpu_block(size, block_size)                                                     :253-270
+  cpu_predict(testing, do_unc=True)                                                   :211-251
+  hessian(testing)                                                                    :345-366
+  _set_params(theta) / _prepare_likelihood()                                          :52-75,127-139
+
+``is_gpu=True`` runs the fused HIP kernel through ``_gpu_predict.predict_wrap`` (the same
+twelve-argument boundary the reference crosses at :313-316).  It never falls back to the
+CPU: if the library or the GPU is missing it raises ``GpuPredictUnavailable``.
+``is_gpu=False`` is the reference API's explicit numpy branch and is only taken when the
+caller asks for it.  Training (``learn_hyperparameters``, ``loglikelihood``,
+``partial_devs``, :77-125,141-209) is out of scope of this package;
+``_set_params`` is kept because it produces the hot path's inputs.
+
+Unlike the reference (:7) this module does not import the GPU extension at import time.
+"""
+import numpy as np
+import scipy.spatial.distance as dist
+
+__all__ = ["GaussianProcess"]
+
+
+class GaussianProcess:
+    """Squared-exponential ARD Gaussian-process emulator (predict side)."""
+
+    def __init__(self, inputs, targets):
+        # gp_emulator/GaussianProcess.py:35-51
+        self.inputs = inputs
+        self.targets = targets
+        (self.n, self.D) = self.inputs.shape
+        self._gpu_models = {}
+
+    # ------------------------------------------------------------------ inputs of the path
+    def _prepare_likelihood(self):
+        """Q, invQ, invQt, logdetQ from theta (reference :52-75).  Host LAPACK, run once."""
+        e = np.exp(self.theta)
+        x = np.asarray(self.inputs, dtype=np.float64)
+        Z = np.zeros((self.n, self.n))
+        for d in range(self.D):
+            col = x[:, d]
+            Z = Z + e[d] * (col[None, :] - col[:, None]) ** 2
+        self.Z = e[self.D] * np.exp(-0.5 * Z)
+        self.Q = self.Z + e[self.D + 1] * np.eye(self.n)
+        self.invQ = np.linalg.inv(self.Q)
+        self.invQt = np.dot(self.invQ, self.targets)
+        self.logdetQ = 2.0 * np.sum(np.log(np.diag(np.linalg.cholesky(self.Q))))
+        self._gpu_models = {}
+
+    def _set_params(self, theta):
+        """Set hyper-parameters and precompute what predict needs (reference :127-139)."""
+        self.theta = theta
+        self._prepare_likelihood()
+
+    # ------------------------------------------------------------------ numpy branch
+    def cpu_predict(self, testing, do_unc=True):
+        """The reference API's numpy branch (reference :211-251); explicit, never a fallback."""
+        (nn, D) = testing.shape
+        assert D == self.D
+        expX = np.exp(self.theta)
+        s = np.sqrt(expX[:D])
+        a = dist.cdist(s * self.inputs, s * testing, "sqeuclidean")
+        a = expX[D] * np.exp(-0.5 * a)
+        b = expX[D]
+        mu = np.dot(a.T, self.invQt)
+        if do_unc:
+            var = b - np.sum(a * np.dot(self.invQ, a), axis=0)
+        deriv = np.zeros((nn, D))
+        for d in range(D):
+            aa = self.inputs[:, d].flatten()[None, :] - testing[:, d].flatten()[:, None]
+            deriv[:, d] = expX[d] * np.dot((a * aa.T).T, self.invQt)
+        if do_unc:
+            return mu, var, deriv
+        return mu, deriv
+
+    # ------------------------------------------------------------------ GPU branch
+    def get_gpu_block(self, size, block_size):
+        """Start/end indices of row blocks no wider than ``block_size``; when there is more
+        than one block the last two are re-split evenly (reference :253-270, Python-2
+        integer division at :265)."""
+        size, block_size = int(size), int(block_size)
+        ind_start = np.arange(0, size, block_size, dtype=np.int64)
+        ind_end = np.append(ind_start[1:], size).astype(np.int64)
+        nblocks = len(ind_start)
+        if nblocks > 1:
+            half = (ind_end[nblocks - 1] - ind_start[nblocks - 2]) // 2
+            ind_end[nblocks - 2] = ind_start[nblocks - 2] + half
+            ind_start[nblocks - 1] = ind_end[nblocks - 2]
+        assert np.all(ind_end - ind_start <= block_size)
+        return ind_start, ind_end
+
+    def gpu_predict(self, testing, precision, threshold):
+        """Predict on the GPU in row blocks of at most ``threshold`` rows (reference
+        :273-323): constants flattened and cast to ``precision`` once (:289-292), each
+        block's rows flattened and cast (:300-311), ``predict_wrap`` called with the twelve
+        reference arguments (:313-316), ``deriv`` un-transposed from the boundary's
+        dimension-major layout (:321).  Outputs are float64 whatever ``precision`` is, as
+        in the reference (it appends onto float64 arrays, :318-321).
+
+        ``threshold`` only bounds the block size; the kernel itself has no 2e5-row limit
+        (the reference's came from kernel_matrixExp.cu:29).
+        """
+        from . import _gpu_predict
+        precision = np.dtype(precision).type
+        n_predict, n_inputs = testing.shape
+        n_train = self.inputs.shape[0]
+        theta_size = self.theta.size
+        assert n_inputs == self.D
+
+        inputs = precision(np.asarray(self.inputs).reshape(n_train * n_inputs))
+        invQt = precision(np.asarray(self.invQt).reshape(n_train))
+        invQ = precision(np.asarray(self.invQ).reshape(n_train * n_train))
+        expX = precision(np.exp(self.theta))
+
+        result = np.zeros(n_predict)
+        error = np.zeros(n_predict)
+        deriv = np.zeros((n_predict, n_inputs))
+        ind_start, ind_end = self.get_gpu_block(n_predict, threshold)
+        for block_start, block_end in zip(ind_start, ind_end):
+            n_blk = int(block_end - block_start)
+            testing_block = precision(np.ascontiguousarray(testing[block_start:block_end, :])
+                                      .reshape(n_blk * n_inputs))
+            result_block = np.zeros(n_blk, dtype=precision)
+            error_block = np.zeros(n_blk, dtype=precision)
+            deriv_block = np.zeros(n_blk * n_inputs, dtype=precision)
+            _gpu_predict.predict_wrap(expX, inputs, invQt, invQ, testing_block,
+                                      result_block, error_block, deriv_block,
+                                      n_blk, n_train, n_inputs, theta_size)
+            result[block_start:block_end] = result_block
+            error[block_start:block_end] = error_block
+            deriv[block_start:block_end, :] = deriv_block.reshape(n_inputs, n_blk).T
+        return result, error, deriv
+
+    def predict(self, testing, do_unc=True, is_gpu=False, precision=np.float64, threshold=2e5):
+        """Mean, variance and gradient at ``testing`` (n_predict, n_inputs) (reference
+        :327-341).  ``do_unc`` only affects the numpy branch, as in the reference."""
+        if is_gpu == True:  # noqa: E712  (reference spelling, :338)
+            return self.gpu_predict(testing, precision, threshold=threshold)
+        return self.cpu_predict(testing, do_unc)
+
+    # ------------------------------------------------------------------ device-resident use
+    def gpu_model(self, precision=np.float64, device=0):
+        """Constants packed and uploaded once (cached per precision/device): the form to use
+        when predict is called repeatedly or the test rows already live in HBM."""
+        from . import _lib
+        key = (np.dtype(precision).str, int(device))
+        m = self._gpu_models.get(key)
+        if m is None:
+            ctx = _lib.default_context(device)
+            m = _lib.Model(ctx, np.exp(self.theta), self.inputs, self.invQt, self.invQ, precision)
+            self._gpu_models[key] = m
+        return m
+
+    # ------------------------------------------------------------------ Hessian
+    def hessian(self, testing):
+        """(nn, D, D) Hessian of the mean, numpy (reference :345-366; the reference has no
+        GPU version).  Written as the symmetric rank-N update it is:
+        H = sum_i w_i u_i u_i^T - diag(e) mu,  w = a * invQt,  u_i = e * (x_i - t)."""
+        (nn, D) = testing.shape
+        assert D == self.D
+        expX = np.exp(self.theta)
+        s = np.sqrt(expX[:D])
+        a = expX[D] * np.exp(-0.5 * dist.cdist(s * self.inputs, s * testing, "sqeuclidean"))
+        w = a * np.asarray(self.invQt)[:, None]                      # (n, nn)
+        hess = np.zeros((nn, D, D))
+        u = expX[:D][None, None, :] * (np.asarray(self.inputs)[:, None, :] - testing[None, :, :])
+        for d in range(D):
+            for d2 in range(D):
+                hess[:, d, d2] = np.sum(w * u[:, :, d] * u[:, :, d2], axis=0)
+            hess[:, d, d] -= expX[d] * np.sum(w, axis=0)
+        return hess

@@ -1,0 +1,285 @@
+"""ctypes binding of libgp_predict_hip.so (the C ABI in include/gp_predict_hip.h).
+
+No PyTorch, no GPU framework: device memory, streams and events all go through the
+library.  Loading FAILS LOUDLY (``GpuPredictUnavailable``) when the library has not been
+built or no GPU is visible -- there is no CPU fallback anywhere behind ``is_gpu=True``.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgp_predict_hip.so")
+
+GP_F32, GP_F64 = 0, 1
+GP_DERIV_DMAJOR, GP_DERIV_ROWMAJOR = 0, 1
+
+c_int, c_i64, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_fp = ctypes.POINTER(ctypes.c_float)
+PP = ctypes.POINTER(c_void_p)
+
+# name -> (restype, argtypes); every symbol include/gp_predict_hip.h declares
+SIGNATURES = {
+    "gp_last_error_string": (ctypes.c_char_p, []),
+    "gp_version_string": (ctypes.c_char_p, []),
+    "gp_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "gp_ctx_create": (c_int, [c_int, PP]),
+    "gp_ctx_destroy": (c_int, [c_void_p]),
+    "gp_ctx_synchronize": (c_int, [c_void_p]),
+    "gp_ctx_device_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_i64),
+                                   ctypes.c_char_p, c_int]),
+    "gp_predict_wrap_f64": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
+    "gp_predict_wrap_f32": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
+    "gp_model_create_f64": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
+    "gp_model_create_f32": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
+    "gp_model_destroy": (c_int, [c_void_p]),
+    "gp_model_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5),
+    "gp_predict_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_i64, c_int]),
+    "gp_pack_sizes": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                              ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "gp_pack_model_f64": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),
+    "gp_pack_model_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),
+    "gp_malloc": (c_int, [c_void_p, c_i64, PP]),
+    "gp_free": (c_int, [c_void_p, c_void_p]),
+    "gp_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_i64]),
+    "gp_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_i64]),
+    "gp_memset": (c_int, [c_void_p, c_void_p, c_int, c_i64]),
+    "gp_event_create": (c_int, [c_void_p, PP]),
+    "gp_event_destroy": (c_int, [c_void_p]),
+    "gp_event_record": (c_int, [c_void_p, c_void_p]),
+    "gp_event_elapsed_ms": (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_float)]),
+}
+
+
+class GpuPredictUnavailable(RuntimeError):
+    """The HIP library is missing or unusable.  Never caught inside this package."""
+
+
+class GpuPredictError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen the library and attach signatures (no GPU is touched)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GpuPredictUnavailable(
+                "%s not built; run `python -m gp_emulator_amd.build` (needs hipcc). "
+                "There is no CPU fallback for is_gpu=True." % LIB_PATH)
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise GpuPredictUnavailable("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().gp_last_error_string().decode("utf-8", "replace")
+        raise GpuPredictError("%s failed (status %d): %s" % (what or "gp call", rc, msg))
+
+
+def device_count():
+    n = c_int(0)
+    rc = load().gp_device_count(ctypes.byref(n))
+    if rc != 0:
+        return 0
+    return n.value
+
+
+def _ptr(a):
+    return a.ctypes.data_as(c_void_p)
+
+
+class Context:
+    """One device + one HIP stream (gp_ctx).  Use one per thread / per GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = c_void_p()
+        rc = self.lib.gp_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            msg = self.lib.gp_last_error_string().decode("utf-8", "replace")
+            raise GpuPredictUnavailable("no usable GPU context on device %d: %s" % (device, msg))
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gp_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def synchronize(self):
+        check(self.lib.gp_ctx_synchronize(self.h), "gp_ctx_synchronize")
+
+    def device_info(self):
+        cu, mem = c_int(0), c_i64(0)
+        name = ctypes.create_string_buffer(256)
+        check(self.lib.gp_ctx_device_info(self.h, ctypes.byref(cu), ctypes.byref(mem), name, 256))
+        return dict(compute_units=cu.value, hbm_bytes=mem.value, name=name.value.decode())
+
+    # ---- memory -----------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = c_void_p()
+        check(self.lib.gp_malloc(self.h, int(nbytes), ctypes.byref(p)), "gp_malloc")
+        return p
+
+    def free(self, p):
+        check(self.lib.gp_free(self.h, p), "gp_free")
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(max(arr.nbytes, 1))
+        if arr.nbytes:
+            check(self.lib.gp_memcpy_h2d(self.h, p, _ptr(arr), arr.nbytes), "gp_memcpy_h2d")
+        return p
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.lib.gp_memcpy_h2d(self.h, dptr, _ptr(arr), arr.nbytes), "gp_memcpy_h2d")
+
+    def to_host(self, dptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes:
+            check(self.lib.gp_memcpy_d2h(self.h, _ptr(out), dptr, out.nbytes), "gp_memcpy_d2h")
+        return out
+
+    # ---- events -----------------------------------------------------------------
+    def event(self):
+        e = c_void_p()
+        check(self.lib.gp_event_create(self.h, ctypes.byref(e)), "gp_event_create")
+        return e
+
+    def record(self, ev):
+        check(self.lib.gp_event_record(self.h, ev), "gp_event_record")
+
+    def elapsed_ms(self, e0, e1):
+        ms = ctypes.c_float(0)
+        check(self.lib.gp_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "gp_event_elapsed_ms")
+        return ms.value
+
+    def event_destroy(self, ev):
+        self.lib.gp_event_destroy(ev)
+
+
+class Model:
+    """Per-emulator constants packed and resident in HBM (gp_model)."""
+
+    def __init__(self, ctx, expX, inputs, invQt, invQ, precision=np.float64):
+        self.ctx = ctx
+        self.dtype = np.dtype(precision)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("precision must be float32 or float64, got %r" % (precision,))
+        inputs = np.ascontiguousarray(inputs, dtype=self.dtype)
+        if inputs.ndim != 2:
+            raise ValueError("inputs must be (n_train, n_inputs)")
+        self.n_train, self.n_inputs = inputs.shape
+        expX = np.ascontiguousarray(expX, dtype=self.dtype).ravel()
+        invQt = np.ascontiguousarray(invQt, dtype=self.dtype).ravel()
+        invQ = np.ascontiguousarray(invQ, dtype=self.dtype)
+        if invQ.size != self.n_train ** 2 or invQt.size != self.n_train:
+            raise ValueError("invQ / invQt size does not match n_train")
+        fn = ctx.lib.gp_model_create_f64 if self.dtype == np.float64 else ctx.lib.gp_model_create_f32
+        h = c_void_p()
+        check(fn(ctx.h, _ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ),
+                 self.n_train, self.n_inputs, expX.size, ctypes.byref(h)), "gp_model_create")
+        self.h = h
+
+    def info(self):
+        v = [c_int(0) for _ in range(5)]
+        check(self.ctx.lib.gp_model_info(self.h, *[ctypes.byref(x) for x in v]))
+        return dict(dtype=v[0].value, n_train=v[1].value, n_inputs=v[2].value,
+                    kernel_d=v[3].value, kernel_nb=v[4].value)
+
+    def predict_device(self, d_testing, d_mu, d_var, d_deriv, n_predict,
+                       deriv_layout=GP_DERIV_ROWMAJOR):
+        """Asynchronous launch on the context's stream; all pointers are device pointers."""
+        check(self.ctx.lib.gp_predict_device(self.ctx.h, self.h, d_testing, d_mu, d_var, d_deriv,
+                                             int(n_predict), int(deriv_layout)), "gp_predict_device")
+
+    def predict(self, testing, deriv_layout=GP_DERIV_ROWMAJOR):
+        """Host arrays in, host arrays out, through device buffers owned by this call."""
+        testing = np.ascontiguousarray(testing, dtype=self.dtype)
+        M, D = testing.shape
+        if D != self.n_inputs:
+            raise ValueError("testing has %d columns, model has %d inputs" % (D, self.n_inputs))
+        isz = self.dtype.itemsize
+        if M == 0:
+            shape = (0, D) if deriv_layout == GP_DERIV_ROWMAJOR else (D, 0)
+            return (np.empty(0, self.dtype), np.empty(0, self.dtype), np.empty(shape, self.dtype))
+        d_t = self.ctx.to_device(testing)
+        d_mu = self.ctx.malloc(M * isz)
+        d_var = self.ctx.malloc(M * isz)
+        d_der = self.ctx.malloc(M * D * isz)
+        try:
+            self.predict_device(d_t, d_mu, d_var, d_der, M, deriv_layout)
+            mu = self.ctx.to_host(d_mu, (M,), self.dtype)
+            var = self.ctx.to_host(d_var, (M,), self.dtype)
+            shape = (M, D) if deriv_layout == GP_DERIV_ROWMAJOR else (D, M)
+            deriv = self.ctx.to_host(d_der, shape, self.dtype)
+        finally:
+            for p in (d_t, d_mu, d_var, d_der):
+                self.ctx.free(p)
+        return mu, var, deriv
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gp_model_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def pack_model(expX, inputs, invQt, invQ, precision=np.float64):
+    """Host-only packing (no GPU): returns dict(xa, frags, sd, b, kernel_d, kernel_nb)."""
+    lib = load()
+    dt = np.dtype(precision)
+    inputs = np.ascontiguousarray(inputs, dtype=dt)
+    N, D = inputs.shape
+    expX = np.ascontiguousarray(expX, dtype=dt).ravel()
+    invQt = np.ascontiguousarray(invQt, dtype=dt).ravel()
+    invQ = np.ascontiguousarray(invQ, dtype=dt)
+    kd, knb, xl, fl = c_int(0), c_int(0), c_i64(0), c_i64(0)
+    check(lib.gp_pack_sizes(GP_F64 if dt == np.float64 else GP_F32, N, D, ctypes.byref(kd),
+                            ctypes.byref(knb), ctypes.byref(xl), ctypes.byref(fl)), "gp_pack_sizes")
+    xa = np.zeros(xl.value, dt)
+    fr = np.zeros(fl.value, dt)
+    sd = np.zeros(kd.value, dt)
+    b = np.zeros(1, dt)
+    fn = lib.gp_pack_model_f64 if dt == np.float64 else lib.gp_pack_model_f32
+    check(fn(_ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ), N, D, expX.size,
+             _ptr(xa), _ptr(fr), _ptr(sd), _ptr(b)), "gp_pack_model")
+    return dict(xa=xa, frags=fr, sd=sd, b=b[0], kernel_d=kd.value, kernel_nb=knb.value)
+
+
+_tls = threading.local()
+
+
+def default_context(device=0):
+    """Per-thread context per device for the drop-in entry points (a gp_ctx owns a stream
+    and a scratch buffer, so it is not shared between threads)."""
+    d = getattr(_tls, "ctx", None)
+    if d is None:
+        d = _tls.ctx = {}
+    c = d.get(device)
+    if c is None:
+        c = d[device] = Context(device)
+    return c

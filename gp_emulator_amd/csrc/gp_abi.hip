@@ -1,0 +1,515 @@
+// C ABI of libgp_predict_hip.so: see include/gp_predict_hip.h for the contract and the
+// reference interfaces (file:line) each entry replaces.
+#include "gp_predict_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gp_dispatch.hpp"
+#include "gp_predict_kernel.hpp"
+
+namespace gpk {
+#define GP_DECL(nb)                                                                         \
+  hipError_t launch_predict_f32_##nb(int, const PredictArgs<float>&, int, hipStream_t);     \
+  hipError_t launch_predict_f64_##nb(int, const PredictArgs<double>&, int, hipStream_t);
+GP_FOR_EACH_KERNEL_NB(GP_DECL)
+#undef GP_DECL
+}  // namespace gpk
+
+// ------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(GP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                  __FILE__, __LINE__);                                                \
+  } while (0)
+
+struct gp_ctx {
+  int device;
+  hipStream_t stream;
+  int compute_units;
+  // grow-only device scratch for the host-pointer (predict_wrap) path
+  void* scratch;
+  size_t scratch_bytes;
+};
+
+struct gp_model {
+  int device;
+  int dtype;
+  int n_train, n_inputs;
+  int kernel_d, kernel_nb;
+  void* d_xa;
+  void* d_frags;
+  void* d_sd;
+  double b;
+};
+
+struct gp_event {
+  int device;
+  hipEvent_t ev;
+};
+
+static const int kKernelD[] = {
+#define GP_V(d) d,
+    GP_FOR_EACH_KERNEL_D(GP_V)
+#undef GP_V
+};
+static const int kKernelNB[] = {
+#define GP_V(d) d,
+    GP_FOR_EACH_KERNEL_NB(GP_V)
+#undef GP_V
+};
+
+static int pick_kernel(int n_train, int n_inputs, int* kd, int* knb) {
+  *kd = *knb = -1;
+  for (int d : kKernelD)
+    if (d >= n_inputs) { *kd = d; break; }
+  const int need = (n_train + 15) / 16;
+  for (int nb : kKernelNB)
+    if (nb >= need) { *knb = nb; break; }
+  if (*kd < 0 || *knb < 0)
+    return fail(GP_ERR_UNSUPPORTED,
+                "shape outside the compiled kernel set: n_train=%d (max %d), n_inputs=%d (max %d)",
+                n_train, 16 * GP_MAX_KERNEL_NB, n_inputs, GP_MAX_KERNEL_D);
+  return GP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// host-side packing (double arithmetic, one rounding to T at the end)
+// ------------------------------------------------------------------------------------
+template <typename T>
+static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* invQ, int N,
+                      int D, int theta_size, T* xa, T* frags, T* sd, T* b) {
+  if (!expX || !inputs || !invQt || !invQ || !xa || !frags || !sd || !b)
+    return fail(GP_ERR_INVALID, "null pointer");
+  if (N <= 0 || D <= 0) return fail(GP_ERR_INVALID, "n_train and n_inputs must be positive");
+  if (theta_size < D + 1)
+    return fail(GP_ERR_INVALID, "theta_size=%d < n_inputs+1=%d", theta_size, D + 1);
+  int kd, knb;
+  int rc = pick_kernel(N, D, &kd, &knb);
+  if (rc) return rc;
+  const int DS = gpk::row_stride(kd);
+  const int NP = 16 * knb;
+  // sqrt(e_d): the reference scales both point sets by sqrt(expX[:D]) before cdist
+  // (GaussianProcess.py:232-233; the CUDA path takes the sqrt on the host too,
+  // _gpu_predict.cpp:135-140)
+  std::vector<double> sdd(kd, 0.0);
+  for (int d = 0; d < D; ++d) sdd[d] = std::sqrt((double)expX[d]);
+  for (int d = 0; d < kd; ++d) sd[d] = (T)sdd[d];
+  *b = expX[D];
+  std::memset(xa, 0, sizeof(T) * (size_t)NP * DS);
+  for (int i = 0; i < N; ++i) {
+    for (int d = 0; d < D; ++d) xa[(size_t)i * DS + d] = (T)(sdd[d] * (double)inputs[(size_t)i * D + d]);
+    xa[(size_t)i * DS + kd] = invQt[i];
+  }
+  // S' in fragment order: fragment (I <= J, s), lane l holds
+  //   S'[i = 16 I + own_sub(s, l >> 4)][j = 16 J + (l & 15)]
+  // with S'_IJ = M_IJ + M_JI^T for I < J and M_JJ on the diagonal, so that
+  //   k^T M k = sum_J sum_{I<=J} k_I^T S'_IJ k_J        for ANY matrix M.
+  const int nfp = gpk::frag_count_padded(knb, gpk::kChunk);
+  std::memset(frags, 0, sizeof(T) * (size_t)nfp * 64);
+  for (int J = 0; J < knb; ++J)
+    for (int I = 0; I <= J; ++I)
+      for (int s = 0; s < 4; ++s) {
+        T* f = frags + (size_t)gpk::frag_index(I, J, s) * 64;
+        for (int l = 0; l < 64; ++l) {
+          const int i = gpk::own_index<T>(I, s, l >> 4);
+          const int j = 16 * J + (l & 15);
+          if (i >= N || j >= N) continue;
+          double v = (double)invQ[(size_t)i * N + j];
+          if (I < J) v += (double)invQ[(size_t)j * N + i];
+          f[l] = (T)v;
+        }
+      }
+  return GP_OK;
+}
+
+template <typename T>
+static hipError_t launch(int knb, int kd, const gpk::PredictArgs<T>& a, int grid, hipStream_t s);
+template <>
+hipError_t launch<float>(int knb, int kd, const gpk::PredictArgs<float>& a, int grid, hipStream_t s) {
+  switch (knb) {
+#define GP_CASE(nb) case nb: return gpk::launch_predict_f32_##nb(kd, a, grid, s);
+    GP_FOR_EACH_KERNEL_NB(GP_CASE)
+#undef GP_CASE
+  }
+  return hipErrorInvalidValue;
+}
+template <>
+hipError_t launch<double>(int knb, int kd, const gpk::PredictArgs<double>& a, int grid, hipStream_t s) {
+  switch (knb) {
+#define GP_CASE(nb) case nb: return gpk::launch_predict_f64_##nb(kd, a, grid, s);
+    GP_FOR_EACH_KERNEL_NB(GP_CASE)
+#undef GP_CASE
+  }
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------
+// exported functions
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gp_last_error_string(void) { return g_err; }
+const char* gp_version_string(void) { return "gp_predict_hip 0.1 (gfx950)"; }
+
+int gp_device_count(int* count) {
+  if (!count) return fail(GP_ERR_INVALID, "null pointer");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(GP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return GP_OK;
+}
+
+int gp_ctx_create(int device, gp_ctx** out) {
+  if (!out) return fail(GP_ERR_INVALID, "null pointer");
+  *out = nullptr;
+  int n = 0;
+  int rc = gp_device_count(&n);
+  if (rc) return rc;
+  if (n <= 0) return fail(GP_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(GP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  gp_ctx* c = new (std::nothrow) gp_ctx();
+  if (!c) return fail(GP_ERR_INVALID, "out of host memory");
+  c->device = device;
+  c->compute_units = prop.multiProcessorCount;
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(GP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return GP_OK;
+}
+
+int gp_ctx_destroy(gp_ctx* ctx) {
+  if (!ctx) return GP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return GP_OK;
+}
+
+int gp_ctx_synchronize(gp_ctx* ctx) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return GP_OK;
+}
+
+int gp_ctx_device_info(gp_ctx* ctx, int* compute_units, int64_t* hbm_bytes, char* name, int name_len) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  if (name && name_len > 0) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return GP_OK;
+}
+
+int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,
+                  int64_t* xa_len, int64_t* frags_len) {
+  (void)dtype;
+  int kd, knb;
+  int rc = pick_kernel(n_train, n_inputs, &kd, &knb);
+  if (rc) return rc;
+  if (kernel_d) *kernel_d = kd;
+  if (kernel_nb) *kernel_nb = knb;
+  if (xa_len) *xa_len = (int64_t)16 * knb * gpk::row_stride(kd);
+  if (frags_len) *frags_len = (int64_t)gpk::frag_count_padded(knb, gpk::kChunk) * 64;
+  return GP_OK;
+}
+
+int gp_pack_model_f64(const double* expX, const double* inputs, const double* invQt,
+                      const double* invQ, int n_train, int n_inputs, int theta_size,
+                      double* xa, double* frags, double* sd, double* b) {
+  return pack_model<double>(expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, xa, frags, sd, b);
+}
+int gp_pack_model_f32(const float* expX, const float* inputs, const float* invQt,
+                      const float* invQ, int n_train, int n_inputs, int theta_size,
+                      float* xa, float* frags, float* sd, float* b) {
+  return pack_model<float>(expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, xa, frags, sd, b);
+}
+
+}  // extern "C"
+
+template <typename T>
+static int model_create(gp_ctx* ctx, const T* expX, const T* inputs, const T* invQt,
+                        const T* invQ, int N, int D, int theta_size, gp_model** out) {
+  if (!ctx || !out) return fail(GP_ERR_INVALID, "null context or output");
+  *out = nullptr;
+  int kd, knb;
+  int64_t xa_len, fr_len;
+  int rc = gp_pack_sizes(0, N, D, &kd, &knb, &xa_len, &fr_len);
+  if (rc) return rc;
+  std::vector<T> xa(xa_len), fr(fr_len), sd(kd);
+  T b;
+  rc = pack_model<T>(expX, inputs, invQt, invQ, N, D, theta_size, xa.data(), fr.data(), sd.data(), &b);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  gp_model* m = new (std::nothrow) gp_model();
+  if (!m) return fail(GP_ERR_INVALID, "out of host memory");
+  m->device = ctx->device;
+  m->dtype = sizeof(T) == 8 ? GP_F64 : GP_F32;
+  m->n_train = N;
+  m->n_inputs = D;
+  m->kernel_d = kd;
+  m->kernel_nb = knb;
+  m->b = (double)b;
+  m->d_xa = m->d_frags = m->d_sd = nullptr;
+  hipError_t e = hipMalloc(&m->d_xa, sizeof(T) * xa_len);
+  if (e == hipSuccess) e = hipMalloc(&m->d_frags, sizeof(T) * fr_len);
+  if (e == hipSuccess) e = hipMalloc(&m->d_sd, sizeof(T) * kd);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_xa, xa.data(), sizeof(T) * xa_len, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_frags, fr.data(), sizeof(T) * fr_len, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_sd, sd.data(), sizeof(T) * kd, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host vectors die at return
+  if (e != hipSuccess) {
+    gp_model_destroy(m);
+    return fail(GP_ERR_HIP, "model upload: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return GP_OK;
+}
+
+template <typename T>
+static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_mu,
+                          void* d_var, void* d_deriv, int64_t M, int layout) {
+  gpk::PredictArgs<T> a;
+  a.xa = (const T*)m->d_xa;
+  a.frags = (const T*)m->d_frags;
+  a.sd = (const T*)m->d_sd;
+  a.b = (T)m->b;
+  a.testing = (const T*)d_testing;
+  a.mu = (T*)d_mu;
+  a.var = (T*)d_var;
+  a.deriv = (T*)d_deriv;
+  a.M = M;
+  a.d_actual = m->n_inputs;
+  a.deriv_row_major = layout == GP_DERIV_ROWMAJOR;
+  const int64_t groups = (M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG;
+  // persistent grid: 2 workgroups per CU (the kernel's occupancy), grid-stride over groups
+  int64_t grid = (int64_t)ctx->compute_units * 2;
+  if (grid > groups) grid = groups;
+  hipError_t e = launch<T>(m->kernel_nb, m->kernel_d, a, (int)grid, ctx->stream);
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
+static int ensure_scratch(gp_ctx* ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return GP_OK;
+  if (ctx->scratch) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return GP_OK;
+}
+
+// Host-pointer path = predict_wrap: upload constants + test rows, one launch, download.
+// Rows are processed in slabs so the device scratch stays bounded for any n_predict.
+template <typename T>
+static int predict_wrap(gp_ctx* ctx, const T* expX, const T* inputs, const T* invQt,
+                        const T* invQ, const T* testing, T* result, T* error, T* deriv,
+                        int64_t M, int N, int D, int theta_size) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
+  if (M > 0 && (!testing || !result || !error || !deriv)) return fail(GP_ERR_INVALID, "null pointer");
+  gp_model* m = nullptr;
+  int rc = model_create<T>(ctx, expX, inputs, invQt, invQ, N, D, theta_size, &m);
+  if (rc) return rc;
+  if (M == 0) { gp_model_destroy(m); return GP_OK; }
+  const int64_t slab = M < (int64_t)(1 << 22) ? M : (int64_t)(1 << 22);  // rows per slab
+  const size_t per_row = sizeof(T) * (size_t)(2 * D + 2);
+  rc = ensure_scratch(ctx, per_row * (size_t)slab);
+  if (rc) { gp_model_destroy(m); return rc; }
+  hipError_t e = hipSuccess;
+  for (int64_t s0 = 0; s0 < M && rc == GP_OK && e == hipSuccess; s0 += slab) {
+    const int64_t n = (M - s0 < slab) ? (M - s0) : slab;
+    T* d_t = (T*)ctx->scratch;
+    T* d_mu = d_t + (size_t)n * D;
+    T* d_var = d_mu + n;
+    T* d_der = d_var + n;
+    e = hipMemcpyAsync(d_t, testing + (size_t)s0 * D, sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) break;
+    rc = predict_device<T>(ctx, m, d_t, d_mu, d_var, d_der, n, GP_DERIV_DMAJOR);
+    if (rc) break;
+    e = hipMemcpyAsync(result + s0, d_mu, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(error + s0, d_var, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    // deriv is dimension-major over the WHOLE call: row d of the slab goes to d*M + s0
+    for (int d = 0; d < D && e == hipSuccess; ++d)
+      e = hipMemcpyAsync(deriv + (size_t)d * M + s0, d_der + (size_t)d * n, sizeof(T) * (size_t)n,
+                         hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  gp_model_destroy(m);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "predict_wrap: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
+extern "C" {
+
+int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
+                        const double* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
+  return model_create<double>(ctx, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+}
+int gp_model_create_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
+                        const float* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
+  return model_create<float>(ctx, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+}
+
+int gp_model_destroy(gp_model* m) {
+  if (!m) return GP_OK;
+  (void)hipSetDevice(m->device);
+  if (m->d_xa) (void)hipFree(m->d_xa);
+  if (m->d_frags) (void)hipFree(m->d_frags);
+  if (m->d_sd) (void)hipFree(m->d_sd);
+  delete m;
+  return GP_OK;
+}
+
+int gp_model_info(const gp_model* m, int* dtype, int* n_train, int* n_inputs, int* kernel_d, int* kernel_nb) {
+  if (!m) return fail(GP_ERR_INVALID, "null model");
+  if (dtype) *dtype = m->dtype;
+  if (n_train) *n_train = m->n_train;
+  if (n_inputs) *n_inputs = m->n_inputs;
+  if (kernel_d) *kernel_d = m->kernel_d;
+  if (kernel_nb) *kernel_nb = m->kernel_nb;
+  return GP_OK;
+}
+
+int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing, void* d_mu,
+                      void* d_var, void* d_deriv, int64_t n_predict, int deriv_layout) {
+  if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
+  if (n_predict < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
+  if (n_predict == 0) return GP_OK;
+  if (!d_testing || !d_mu || !d_var || !d_deriv) return fail(GP_ERR_INVALID, "null device pointer");
+  if (deriv_layout != GP_DERIV_DMAJOR && deriv_layout != GP_DERIV_ROWMAJOR)
+    return fail(GP_ERR_INVALID, "bad deriv_layout %d", deriv_layout);
+  if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (model->dtype == GP_F64)
+    return predict_device<double>(ctx, model, d_testing, d_mu, d_var, d_deriv, n_predict, deriv_layout);
+  return predict_device<float>(ctx, model, d_testing, d_mu, d_var, d_deriv, n_predict, deriv_layout);
+}
+
+int gp_predict_wrap_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
+                        const double* invQ, const double* testing, double* result, double* error,
+                        double* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
+  return predict_wrap<double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                              n_predict, n_train, n_inputs, theta_size);
+}
+int gp_predict_wrap_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
+                        const float* invQ, const float* testing, float* result, float* error,
+                        float* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
+  return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                             n_predict, n_train, n_inputs, theta_size);
+}
+
+int gp_malloc(gp_ctx* ctx, int64_t bytes, void** dptr) {
+  if (!ctx || !dptr) return fail(GP_ERR_INVALID, "null pointer");
+  if (bytes <= 0) return fail(GP_ERR_INVALID, "bytes must be positive");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMalloc(dptr, (size_t)bytes));
+  return GP_OK;
+}
+int gp_free(gp_ctx* ctx, void* dptr) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  if (!dptr) return GP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipFree(dptr));
+  return GP_OK;
+}
+int gp_memcpy_h2d(gp_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  if (!ctx || !dst || !src) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return GP_OK;
+}
+int gp_memcpy_d2h(gp_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  if (!ctx || !dst || !src) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return GP_OK;
+}
+int gp_memset(gp_ctx* ctx, void* dptr, int value, int64_t bytes) {
+  if (!ctx || !dptr) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemsetAsync(dptr, value, (size_t)bytes, ctx->stream));
+  return GP_OK;
+}
+
+int gp_event_create(gp_ctx* ctx, gp_event** out) {
+  if (!ctx || !out) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  gp_event* e = new (std::nothrow) gp_event();
+  if (!e) return fail(GP_ERR_INVALID, "out of host memory");
+  e->device = ctx->device;
+  hipError_t r = hipEventCreate(&e->ev);
+  if (r != hipSuccess) {
+    delete e;
+    return fail(GP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(r));
+  }
+  *out = e;
+  return GP_OK;
+}
+int gp_event_destroy(gp_event* ev) {
+  if (!ev) return GP_OK;
+  (void)hipSetDevice(ev->device);
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return GP_OK;
+}
+int gp_event_record(gp_ctx* ctx, gp_event* ev) {
+  if (!ctx || !ev) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipEventRecord(ev->ev, ctx->stream));
+  return GP_OK;
+}
+int gp_event_elapsed_ms(gp_event* start, gp_event* stop, float* ms) {
+  if (!start || !stop || !ms) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(stop->device));
+  HIP_TRY(hipEventSynchronize(stop->ev));
+  HIP_TRY(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return GP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+/* gp_predict_hip.h -- C ABI of libgp_predict_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the GP predict hot path of UCL/gp_emulator.  The reference's only
+ * native entry point for this path is the CPython-2 extension function
+ *
+ *     _gpu_predict.predict_wrap(expX, inputs, invQt, invQ, testing,
+ *                               result, error, deriv,
+ *                               n_predict, n_train, n_inputs, theta_size)
+ *
+ * (gp_emulator/gpu/_gpu_predict.cpp:115-159, argument parse :86-95, declaration
+ * gp_emulator/gpu/gpu_predict.h:46), called from GaussianProcess.gpu_predict
+ * (gp_emulator/GaussianProcess.py:313-316).  gp_predict_wrap_f32/_f64 below take exactly
+ * those twelve arguments (plus a context handle) with exactly that meaning and layout.
+ * Everything else here is the device-resident form of the same path (constants uploaded
+ * once, test rows and outputs living in HBM), which the reference does not have because it
+ * re-uploads everything per call (gp_emulator/gpu/predict.cu:11-34).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative gp_status; the message for the calling thread's last failure is
+ * gp_last_error_string().  Nothing here ever calls exit() (the reference does:
+ * _gpu_predict.cpp:45-56, kernel_cdist.cu:28-32, kernel_matrixExp.cu:23-33).
+ * All 2-D data is row-major and flattened, as at the reference boundary
+ * (GaussianProcess.py:289-291,301).
+ */
+#ifndef GP_PREDICT_HIP_H
+#define GP_PREDICT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gp_status {
+  GP_OK = 0,
+  GP_ERR_INVALID = -1,      /* bad argument (null pointer, size <= 0, unsupported shape) */
+  GP_ERR_HIP = -2,          /* a HIP runtime call failed (see gp_last_error_string) */
+  GP_ERR_NO_DEVICE = -3,    /* no usable GPU */
+  GP_ERR_UNSUPPORTED = -4   /* shape outside the compiled kernel set */
+} gp_status;
+
+typedef enum gp_dtype { GP_F32 = 0, GP_F64 = 1 } gp_dtype;
+
+/* deriv output layouts */
+#define GP_DERIV_DMAJOR 0   /* element (d, m) at d*M + m: the reference boundary's layout
+                               (predict.cu:139-150, undone at GaussianProcess.py:321) */
+#define GP_DERIV_ROWMAJOR 1 /* (M, D) row-major: what GaussianProcess.predict returns */
+
+typedef struct gp_ctx gp_ctx;     /* one per (thread, device): device id + HIP stream */
+typedef struct gp_model gp_model; /* packed per-emulator constants resident in HBM */
+typedef struct gp_event gp_event; /* HIP event on the context's stream */
+
+/* ---- library / device ---------------------------------------------------------------- */
+const char* gp_last_error_string(void);
+const char* gp_version_string(void);
+int gp_device_count(int* count);
+
+int gp_ctx_create(int device, gp_ctx** out);
+int gp_ctx_destroy(gp_ctx* ctx);
+int gp_ctx_synchronize(gp_ctx* ctx);
+/* number of compute units and HBM bytes of the context's device */
+int gp_ctx_device_info(gp_ctx* ctx, int* compute_units, int64_t* hbm_bytes, char* name, int name_len);
+
+/* ---- the reference boundary: predict_wrap --------------------------------------------
+ * Replaces _gpu_predict.predict_wrap (gp_emulator/gpu/_gpu_predict.cpp:115-159).
+ *   expX      [theta_size]         exp(theta); expX[n_inputs] is the signal variance b
+ *   inputs    [n_train*n_inputs]   training inputs, row-major
+ *   invQt     [n_train]            invQ . targets
+ *   invQ      [n_train*n_train]    row-major; ANY matrix (tests/benchmark.py:14 feeds a
+ *                                  random non-symmetric one)
+ *   testing   [n_predict*n_inputs] test rows, row-major
+ *   result    [n_predict]          out: mean
+ *   error     [n_predict]          out: variance  b - k^T invQ k
+ *   deriv     [n_inputs*n_predict] out: gradient, DIMENSION-MAJOR (GP_DERIV_DMAJOR)
+ * Host pointers in, host pointers out; the call returns when the outputs are written.
+ * Differences from the reference, all relaxations: n_predict is 64-bit and has no minimum
+ * (reference: >= 1000, kernel_cdist.cu:28) and no n_train*n_predict <= 67.1M cap
+ * (kernel_matrixExp.cu:29); both precisions live in one library (reference: one per build,
+ * CMakeLists.txt:8-12). */
+int gp_predict_wrap_f64(gp_ctx* ctx, const double* expX, const double* inputs,
+                        const double* invQt, const double* invQ, const double* testing,
+                        double* result, double* error, double* deriv,
+                        int64_t n_predict, int n_train, int n_inputs, int theta_size);
+int gp_predict_wrap_f32(gp_ctx* ctx, const float* expX, const float* inputs,
+                        const float* invQt, const float* invQ, const float* testing,
+                        float* result, float* error, float* deriv,
+                        int64_t n_predict, int n_train, int n_inputs, int theta_size);
+
+/* ---- device-resident form --------------------------------------------------------------
+ * gp_model_create_*: pack (host side, in double) and upload the per-emulator constants the
+ * reference re-uploads for every block (predict.cu:17-33): sqrt(e)-scaled training inputs
+ * + invQt, and invQ folded to S' in matrix-core fragment order.  compute dtype = the
+ * function's dtype. */
+int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs,
+                        const double* invQt, const double* invQ,
+                        int n_train, int n_inputs, int theta_size, gp_model** out);
+int gp_model_create_f32(gp_ctx* ctx, const float* expX, const float* inputs,
+                        const float* invQt, const float* invQ,
+                        int n_train, int n_inputs, int theta_size, gp_model** out);
+int gp_model_destroy(gp_model* model);
+int gp_model_info(const gp_model* model, int* dtype, int* n_train, int* n_inputs,
+                  int* kernel_d, int* kernel_nb);
+
+/* One launch of the fused kernel on the context's stream (asynchronous).  d_testing,
+ * d_mu, d_var, d_deriv are DEVICE pointers of the model's dtype: testing [M*D] row-major,
+ * mu [M], var [M], deriv [M*D] in deriv_layout. */
+int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
+                      void* d_mu, void* d_var, void* d_deriv, int64_t n_predict,
+                      int deriv_layout);
+
+/* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  Buffers are
+ * sized by gp_pack_sizes; used by the CPU tests to check the fragment layout. */
+int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,
+                  int64_t* xa_len, int64_t* frags_len);
+int gp_pack_model_f64(const double* expX, const double* inputs, const double* invQt,
+                      const double* invQ, int n_train, int n_inputs, int theta_size,
+                      double* xa, double* frags, double* sd, double* b);
+int gp_pack_model_f32(const float* expX, const float* inputs, const float* invQt,
+                      const float* invQ, int n_train, int n_inputs, int theta_size,
+                      float* xa, float* frags, float* sd, float* b);
+
+/* ---- device memory and timing plumbing (so the Python host needs no GPU framework) --- */
+int gp_malloc(gp_ctx* ctx, int64_t bytes, void** dptr);
+int gp_free(gp_ctx* ctx, void* dptr);
+int gp_memcpy_h2d(gp_ctx* ctx, void* dst_device, const void* src_host, int64_t bytes);
+int gp_memcpy_d2h(gp_ctx* ctx, void* dst_host, const void* src_device, int64_t bytes);
+int gp_memset(gp_ctx* ctx, void* dptr, int value, int64_t bytes);
+int gp_event_create(gp_ctx* ctx, gp_event** out);
+int gp_event_destroy(gp_event* ev);
+int gp_event_record(gp_ctx* ctx, gp_event* ev);   /* on the context's stream */
+int gp_event_elapsed_ms(gp_event* start, gp_event* stop, float* ms); /* syncs on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GP_PREDICT_HIP_H */

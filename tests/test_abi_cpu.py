@@ -1,0 +1,171 @@
+"""CPU-side checks of the boundary: the library loads and exports every symbol the header
+declares, the host-side packing realises the identity the kernel relies on, and the Python
+host logic mirrors the reference.  No compute call needs a GPU here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synthetic_case
+from oracle import gp_oracle
+
+from gp_emulator_amd import GaussianProcess, _gpu_predict, _lib
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "gp_predict_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libgp_predict_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "no ctypes signature for %s" % n
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.gp_version_string()
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    """On a box without a GPU is_gpu=True must raise, never compute on the CPU."""
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = synthetic_case("odd_n37_d3")
+    gp = GaussianProcess(g["inputs"], [])
+    gp.theta, gp.invQ, gp.invQt = g["theta"], g["invQ"], g["invQt"]
+    with pytest.raises(_lib.GpuPredictUnavailable):
+        gp.predict(g["testing"], is_gpu=True)
+    with pytest.raises(_lib.GpuPredictUnavailable):
+        gp.gpu_model()
+
+
+def mfma_rows(dtype):
+    """own_sub(r, g): row inside a 16-block of C/D register r for lane group g."""
+    if np.dtype(dtype) == np.float64:
+        return lambda r, g: 4 * r + g
+    return lambda r, g: 4 * g + r
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["odd_n37_d3", "c1_n100_d5", "c2_n250_d11", "c4_n300_d11"])
+def test_packed_fragments_reproduce_quadratic_form(name, dtype):
+    """Emulate, in numpy, exactly what the kernel does with the packed buffers:
+    16x16x4 matrix-core steps over block pairs I <= J, operands taken lane by lane from
+    the fragment buffer, result rows read back per lane -- and check
+    k^T invQ k (invQ NON-symmetric) and mean/gradient against the oracle."""
+    g = synthetic_case(name)
+    N, D = g["inputs"].shape
+    pk = _lib.pack_model(np.exp(g["theta"]), g["inputs"], g["invQt"], g["invQ"], dtype)
+    kd, nb = pk["kernel_d"], pk["kernel_nb"]
+    assert kd >= D and 16 * nb >= N
+    ds = (kd + 1 + 3) & ~3
+    xa = pk["xa"].astype(np.float64).reshape(16 * nb, ds)
+    frags = pk["frags"].astype(np.float64).reshape(-1, 64)
+    sd = pk["sd"].astype(np.float64)
+    own = mfma_rows(dtype)
+    lanes = np.arange(64)
+    grp, col = lanes >> 4, lanes & 15
+
+    T = g["testing"][:16]
+    tp = np.zeros((16, kd))
+    tp[:, :D] = sd[:D] * T
+    # K tile, mean, gradient the way phase A forms them
+    dl = xa[:, None, :kd] - tp[None, :, :]                    # (NP, 16, kd)
+    K = pk["b"] * np.exp(-0.5 * np.sum(dl * dl, axis=2))      # (NP, 16)
+    w = K * xa[:, kd][:, None]
+    mu = w.sum(axis=0)
+    grad = (w[:, :, None] * dl).sum(axis=0)[:, :D] * sd[:D]
+    # phase B
+    quad = np.zeros(16)
+    for J in range(nb):
+        acc = np.zeros((16, 16))                              # [row j_local][col m]
+        for I in range(J + 1):
+            for s in range(4):
+                f = frags[(J * (J + 1) // 2 + I) * 4 + s]
+                A = np.zeros((16, 4))
+                A[col, grp] = f                               # A[row = l&15][k = l>>4]
+                i_of_k = np.array([16 * I + own(s, gq) for gq in range(4)])
+                B = K[i_of_k, :]                              # B[k][col = m]
+                acc += A @ B
+        for gq in range(4):
+            for r in range(4):
+                quad += acc[own(r, gq), :] * K[16 * J + own(r, gq), :]
+    var = pk["b"] - quad
+    o_mu, o_var, o_der = gp_oracle.cpu_predict(g["inputs"], g["theta"], g["invQ"], g["invQt"], T)
+    tol = 1e-12 if np.dtype(dtype) == np.float64 else 2e-6
+    assert gp_oracle.maxnorm_err(o_mu, mu) < tol
+    assert gp_oracle.maxnorm_err(o_var, var) < tol
+    assert gp_oracle.maxnorm_err(o_der, grad) < tol
+
+
+def test_pack_rejects_unsupported_shapes():
+    with pytest.raises(_lib.GpuPredictError):
+        _lib.pack_model(np.ones(40), np.zeros((10, 38)), np.zeros(10), np.zeros((10, 10)))
+    with pytest.raises(_lib.GpuPredictError):
+        _lib.pack_model(np.ones(4), np.zeros((5000, 2)), np.zeros(5000), np.zeros((5000, 5000)))
+
+
+BLOCK_CASES = [(250000, 100000), (200000, 100000), (1000, 200000), (200001, 100000),
+               (300001, 100000), (7, 3), (1, 5), (100000, 1e5), (900000, 1e5)]
+
+
+@pytest.mark.parametrize("args", BLOCK_CASES)
+def test_get_gpu_block_matches_oracle(args):
+    gp = GaussianProcess(np.zeros((3, 2)), [])
+    s, e = gp.get_gpu_block(*args)
+    os_, oe = gp_oracle.get_gpu_block(*args)
+    assert list(s) == list(os_) and list(e) == list(oe)
+
+
+def test_host_numpy_branch_and_hessian_match_oracle():
+    g = synthetic_case("odd_n37_d3")
+    gp = GaussianProcess(g["inputs"], [])
+    gp.theta, gp.invQ, gp.invQt = g["theta"], g["invQ"], g["invQt"]
+    mu, var, der = gp.predict(g["testing"])
+    assert gp_oracle.maxnorm_err(g["mu"], mu) < 1e-13
+    assert gp_oracle.maxnorm_err(g["var"], var) < 1e-13
+    assert gp_oracle.maxnorm_err(g["deriv"], der) < 1e-13
+    mu2, der2 = gp.predict(g["testing"], do_unc=False)
+    assert np.array_equal(mu, mu2)
+    h = gp.hessian(g["testing"][:33])
+    assert gp_oracle.maxnorm_err(g["hess"], h) < 1e-12
+
+
+def test_set_params_matches_oracle():
+    from conftest import load_golden
+    g = load_golden("prosail_pc0")
+    gp = GaussianProcess(g["inputs"], g["targets"])
+    gp._set_params(g["theta"])
+    pl = gp_oracle.prepare_likelihood(g["inputs"], g["targets"], g["theta"])
+    assert np.max(np.abs(gp.invQ - pl["invQ"])) / np.max(np.abs(pl["invQ"])) < 1e-6
+    assert np.max(np.abs(gp.invQt - pl["invQt"])) / np.max(np.abs(pl["invQt"])) < 1e-6
+    assert abs(gp.logdetQ - pl["logdetQ"]) < 1e-6 * abs(pl["logdetQ"])
+
+
+def test_predict_wrap_argument_checks():
+    """The reference exit()s on a wrong dtype/ndim (_gpu_predict.cpp:39-58); the shim raises."""
+    f = np.zeros(4, np.float64)
+    good = [np.ones(3), np.zeros(2), np.zeros(2), np.zeros(4), np.zeros(2), np.zeros(2),
+            np.zeros(2), np.zeros(2)]
+    bad = list(good)
+    bad[4] = np.zeros(2, np.float32)
+    with pytest.raises(TypeError):
+        _gpu_predict.predict_wrap(*bad, 2, 2, 1, 3)
+    bad = list(good)
+    bad[1] = np.zeros((2, 1))
+    with pytest.raises(ValueError):
+        _gpu_predict.predict_wrap(*bad, 2, 2, 1, 3)
+    bad = list(good)
+    bad[0] = np.ones(3, np.int64)
+    with pytest.raises(TypeError):
+        _gpu_predict.predict_wrap(*[a.astype(np.int64) for a in good], 2, 2, 1, 3)
+    with pytest.raises(ValueError):
+        _gpu_predict.predict_wrap(*good, 5, 2, 1, 3)   # outputs too short for n_predict
+    with pytest.raises(TypeError):
+        _gpu_predict.predict_wrap([1.0, 2, 3], *good[1:], 2, 2, 1, 3)
+    del f
