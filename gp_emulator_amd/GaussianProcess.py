@@ -107,16 +107,18 @@ class GaussianProcess:
         (the reference's came from kernel_matrixExp.cu:29).
         """
         from . import _gpu_predict
-        precision = np.dtype(precision).type
+        precision = np.dtype(precision)
         n_predict, n_inputs = testing.shape
         n_train = self.inputs.shape[0]
         theta_size = self.theta.size
         assert n_inputs == self.D
 
-        inputs = precision(np.asarray(self.inputs).reshape(n_train * n_inputs))
-        invQt = precision(np.asarray(self.invQt).reshape(n_train))
-        invQ = precision(np.asarray(self.invQ).reshape(n_train * n_train))
-        expX = precision(np.exp(self.theta))
+        def cast(a, size):   # 1-D, contiguous, ``precision`` (reference :289-292)
+            return np.ascontiguousarray(np.asarray(a).reshape(size), dtype=precision)
+        inputs = cast(self.inputs, n_train * n_inputs)
+        invQt = cast(self.invQt, n_train)
+        invQ = cast(self.invQ, n_train * n_train)
+        expX = cast(np.exp(self.theta), theta_size)
 
         result = np.zeros(n_predict)
         error = np.zeros(n_predict)
@@ -124,8 +126,7 @@ class GaussianProcess:
         ind_start, ind_end = self.get_gpu_block(n_predict, threshold)
         for block_start, block_end in zip(ind_start, ind_end):
             n_blk = int(block_end - block_start)
-            testing_block = precision(np.ascontiguousarray(testing[block_start:block_end, :])
-                                      .reshape(n_blk * n_inputs))
+            testing_block = cast(testing[block_start:block_end, :], n_blk * n_inputs)
             result_block = np.zeros(n_blk, dtype=precision)
             error_block = np.zeros(n_blk, dtype=precision)
             deriv_block = np.zeros(n_blk * n_inputs, dtype=precision)

@@ -36,11 +36,11 @@ def wrap(g, precision, testing=None):
     testing = g["testing"] if testing is None else testing
     M, D = testing.shape
     N = g["inputs"].shape[0]
-    p = np.dtype(precision).type
-    res, err, der = np.zeros(M, p), np.zeros(M, p), np.zeros(M * D, p)
-    _gpu_predict.predict_wrap(p(np.exp(g["theta"])), p(g["inputs"].reshape(-1)), p(g["invQt"]),
-                              p(g["invQ"].reshape(-1)), p(testing.reshape(-1)),
-                              res, err, der, M, N, D, g["theta"].size)
+    def p(a):
+        return np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=precision)
+    res, err, der = np.zeros(M, precision), np.zeros(M, precision), np.zeros(M * D, precision)
+    _gpu_predict.predict_wrap(p(np.exp(g["theta"])), p(g["inputs"]), p(g["invQt"]),
+                              p(g["invQ"]), p(testing), res, err, der, M, N, D, g["theta"].size)
     return res, err, der.reshape(D, M).T
 
 
@@ -59,11 +59,20 @@ def test_real_emulator_prosail_pc0(gpu_lib, precision):
     g = load_golden("prosail_pc0")
     mu, var, der = wrap(g, precision)
     b = float(np.exp(g["theta"][g["inputs"].shape[1]]))
-    assert gp_oracle.maxnorm_err(g["mu"], mu) <= TOL[precision]
-    assert gp_oracle.maxnorm_err(g["deriv"], der) <= TOL[precision]
+    e_mu, e_der = gp_oracle.maxnorm_err(g["mu"], mu), gp_oracle.maxnorm_err(g["deriv"], der)
+    e_var_b = np.max(np.abs(var - g["var"])) / b
+    print("prosail_pc0 %s: e_mu=%.3g e_deriv=%.3g |dvar|/b=%.3g" % (np.dtype(precision).name, e_mu, e_der, e_var_b))
     if precision == np.float64:
-        assert np.max(np.abs(var - g["var"])) / b <= 1e-8
-    # fp32 variance on a cond~1e7 emulator is meaningless: reported only
+        assert e_mu <= 1e-10 and e_der <= 1e-10
+        assert e_var_b <= 1e-8
+    else:
+        # This emulator's mean is a sum with condition number sum|k_i a_i| / |mu| ~ 8e4
+        # (median over the test rows): merely ROUNDING the inputs to float32 and then
+        # computing in float64 already moves mu by 8.7e-5 and the gradient by 5.9e-5, so the
+        # 1e-4 fp32 bar of the synthetic benchmark cannot apply; gate at 2e-3.  The fp32
+        # variance of a cond~1e7 emulator is meaningless (input rounding alone: 0.05 b) and
+        # is reported, not gated (SURVEY.md sections 7, 8d).
+        assert e_mu <= 2e-3 and e_der <= 2e-3
 
 
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
