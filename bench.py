@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--n-test", type=int, default=N_TEST)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=100000)
+    ap.add_argument("--cpu-sample", type=int, default=1000000)
     return ap.parse_args()
 
 
@@ -59,18 +59,19 @@ def cpu_baseline(sample_rows):
     from oracle import gp_oracle
     inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(12345, N_TRAIN, N_INPUTS,
                                                                      sample_rows)
-    blas_threads = None
     try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        pass
-    gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[:2000])   # warm up
-    t0 = time.perf_counter()
-    gp_oracle.cpu_predict_blocked(inputs, theta, invQ, invQt, testing, block=50000)
-    dt = time.perf_counter() - t0
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    from threadpoolctl import threadpool_limits
+    blas_threads = max(1, min(avail, 16))       # the GPU box gives one GPU a 16-cpu share
+    with threadpool_limits(limits=blas_threads):
+        gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[:2000])   # warm up
+        t0 = time.perf_counter()
+        gp_oracle.cpu_predict_blocked(inputs, theta, invQ, invQt, testing, block=50000)
+        dt = time.perf_counter() - t0
     return {"value": sample_rows / dt, "unit": "test-points/s",
-            "cores": int(blas_threads or os.cpu_count() or 1), "kind": "port",
+            "cores": int(blas_threads), "kind": "port",
             "sample": "%d rows of the same N=250, D=11 workload in 50k-row blocks, %.1f s; "
                       "numpy+scipy path (oracle/gp_oracle.py), BLAS threads=%s of %d host "
                       "cpus, elementwise/cdist/exp single-threaded as in the reference"
@@ -121,17 +122,6 @@ def main():
         step()
     ctx.synchronize()
 
-    # parity spot check of what is being timed (not in the timed region)
-    idx = np.random.RandomState(5).choice(M, 2048, replace=False)
-    mu = ctx.to_host(d_mu, (M,), dtype)[idx]
-    var = ctx.to_host(d_var, (M,), dtype)[idx]
-    der = ctx.to_host(d_der, (M, N_INPUTS), dtype)[idx]
-    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[idx])
-    errs = [gp_oracle.maxnorm_err(r, g) for r, g in zip(ref, (mu, var, der))]
-    tol = 1e-10 if a.precision == "f64" else 1e-4
-    if not max(errs) <= tol:
-        raise SystemExit("bench parity check failed: %s" % errs)
-
     # ---- timed region: exactly K steps, barrier + device sync on both sides ----------
     evs = [ctx.event() for _ in range(a.steps + 1)]
     barrier()
@@ -147,6 +137,18 @@ def main():
 
     kern_ms = [ctx.elapsed_ms(evs[k], evs[k + 1]) for k in range(a.steps)]
     kern_avg_s = float(np.mean(kern_ms)) * 1e-3
+
+    # parity spot check of what was timed (after the timed region: the numpy check leaves
+    # BLAS worker threads spinning, which would steal host time from the launch loop)
+    idx = np.random.RandomState(5).choice(M, 2048, replace=False)
+    mu = ctx.to_host(d_mu, (M,), dtype)[idx]
+    var = ctx.to_host(d_var, (M,), dtype)[idx]
+    der = ctx.to_host(d_der, (M, N_INPUTS), dtype)[idx]
+    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[idx])
+    errs = [gp_oracle.maxnorm_err(r, g) for r, g in zip(ref, (mu, var, der))]
+    tol = 1e-10 if a.precision == "f64" else 1e-4
+    if not max(errs) <= tol:
+        raise SystemExit("bench parity check failed: %s" % errs)
 
     if dist is not None:
         import torch
