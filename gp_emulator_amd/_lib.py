@@ -262,12 +262,13 @@ def pack_model(expX, inputs, invQt, invQ, precision=np.float64):
                             ctypes.byref(knb), ctypes.byref(xl), ctypes.byref(fl)), "gp_pack_sizes")
     xa = np.zeros(xl.value, dt)
     fr = np.zeros(fl.value, dt)
-    sd = np.zeros(kd.value, dt)
+    sd = np.zeros(2 * kd.value, dt)
     b = np.zeros(1, dt)
     fn = lib.gp_pack_model_f64 if dt == np.float64 else lib.gp_pack_model_f32
     check(fn(_ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ), N, D, expX.size,
              _ptr(xa), _ptr(fr), _ptr(sd), _ptr(b)), "gp_pack_model")
-    return dict(xa=xa, frags=fr, sd=sd, b=b[0], kernel_d=kd.value, kernel_nb=knb.value)
+    return dict(xa=xa, frags=fr, sd=sd[:kd.value], centre=sd[kd.value:], b=b[0],
+                kernel_d=kd.value, kernel_nb=knb.value)
 
 
 _tls = threading.local()

@@ -111,15 +111,33 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
   const int NP = 16 * knb;
   // sqrt(e_d): the reference scales both point sets by sqrt(expX[:D]) before cdist
   // (GaussianProcess.py:232-233; the CUDA path takes the sqrt on the host too,
-  // _gpu_predict.cpp:135-140)
-  std::vector<double> sdd(kd, 0.0);
-  for (int d = 0; d < D; ++d) sdd[d] = std::sqrt((double)expX[d]);
-  for (int d = 0; d < kd; ++d) sd[d] = (T)sdd[d];
+  // _gpu_predict.cpp:135-140).  Both sets are also shifted by the training mean c_d first:
+  // distances are unchanged and the kernel's expansion
+  //   -|x''-t''|^2/2 = h_i + g + x''.t''   cancels less the smaller |x''|, |t''| are.
+  std::vector<double> sdd(kd, 0.0), ctr(kd, 0.0);
+  for (int d = 0; d < D; ++d) {
+    sdd[d] = std::sqrt((double)expX[d]);
+    double sum = 0.0;
+    for (int i = 0; i < N; ++i) sum += (double)inputs[(size_t)i * D + d];
+    ctr[d] = (double)(T)(sum / N);     // representable in T: the kernel subtracts it in T
+  }
+  for (int d = 0; d < kd; ++d) {
+    sd[d] = (T)sdd[d];
+    sd[kd + d] = (T)ctr[d];
+  }
   *b = expX[D];
+  const double lnb = std::log((double)expX[D]);
   std::memset(xa, 0, sizeof(T) * (size_t)NP * DS);
   for (int i = 0; i < N; ++i) {
-    for (int d = 0; d < D; ++d) xa[(size_t)i * DS + d] = (T)(sdd[d] * (double)inputs[(size_t)i * D + d]);
+    double n2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      // the kernel works with the ROUNDED x'' (type T), so h must be built from it too
+      const T xr = (T)((double)sd[d] * ((double)inputs[(size_t)i * D + d] - ctr[d]));
+      xa[(size_t)i * DS + d] = xr;
+      n2 += (double)xr * (double)xr;
+    }
     xa[(size_t)i * DS + kd] = invQt[i];
+    xa[(size_t)i * DS + kd + 1] = (T)(lnb - 0.5 * n2);
   }
   // S' in fragment order: fragment (I <= J, s), lane l holds
   //   S'[i = 16 I + own_sub(s, l >> 4)][j = 16 J + (l & 15)]
@@ -274,7 +292,7 @@ static int model_create(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   int64_t xa_len, fr_len;
   int rc = gp_pack_sizes(0, N, D, &kd, &knb, &xa_len, &fr_len);
   if (rc) return rc;
-  std::vector<T> xa(xa_len), fr(fr_len), sd(kd);
+  std::vector<T> xa(xa_len), fr(fr_len), sd(2 * kd);
   T b;
   rc = pack_model<T>(expX, inputs, invQt, invQ, N, D, theta_size, xa.data(), fr.data(), sd.data(), &b);
   if (rc) return rc;
@@ -291,10 +309,10 @@ static int model_create(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   m->d_xa = m->d_frags = m->d_sd = nullptr;
   hipError_t e = hipMalloc(&m->d_xa, sizeof(T) * xa_len);
   if (e == hipSuccess) e = hipMalloc(&m->d_frags, sizeof(T) * fr_len);
-  if (e == hipSuccess) e = hipMalloc(&m->d_sd, sizeof(T) * kd);
+  if (e == hipSuccess) e = hipMalloc(&m->d_sd, sizeof(T) * 2 * kd);
   if (e == hipSuccess) e = hipMemcpyAsync(m->d_xa, xa.data(), sizeof(T) * xa_len, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(m->d_frags, fr.data(), sizeof(T) * fr_len, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(m->d_sd, sd.data(), sizeof(T) * kd, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_sd, sd.data(), sizeof(T) * 2 * kd, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host vectors die at return
   if (e != hipSuccess) {
     gp_model_destroy(m);

@@ -53,16 +53,47 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <typename T> struct Real;
 template <> struct Real<double> {
   typedef f64x4 acc_t;
+  // phase A in expansion form (k = exp(h_i + g + x''.t''), 2 fma per point and dimension):
+  // the cancellation costs ~|x''|^2 ulps of 1e-16, far inside the 1e-10 fp64 bar
+  static constexpr bool kExpand = true;
   // row (within a 16-block) of C/D register r for lane group g:
   // v_mfma_f64_16x16x4_f64: row = g + 4 r   (cdna_hip_programming.md section 3)
   __host__ __device__ static constexpr int own_sub(int r, int g) { return 4 * r + g; }
   __device__ static inline acc_t mfma(double a, double b, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
-  __device__ static inline double exp_(double x) { return exp(x); }
+  // exp for arguments that are <= 0 up to rounding (-0.5 * squared distance + ln b):
+  // n = rint(x / ln2), r = x - n ln2 (two-step, fma), exp(r) by a degree-12 Taylor Horner
+  // chain (|r| <= 0.3466: truncation 1.7e-16 relative), scaled by v_ldexp_f64, which also
+  // delivers the gradual underflow to 0.  No overflow path is needed; the lower clamp only
+  // keeps n inside int32 for absurdly distant points and lets NaN inputs through as NaN.
+  __device__ static inline double exp_(double x) {
+    x = (x < -1000.0) ? -1000.0 : x;
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(n, -6.93147180559945286e-01, x);
+    r = fma(n, -2.31904681384629956e-17, r);
+    double p = 2.08767569878680990e-09;        // 1/12!
+    p = fma(p, r, 2.50521083854417188e-08);    // 1/11!
+    p = fma(p, r, 2.75573192239858907e-07);    // 1/10!
+    p = fma(p, r, 2.75573192239858907e-06);    // 1/9!
+    p = fma(p, r, 2.48015873015873016e-05);    // 1/8!
+    p = fma(p, r, 1.98412698412698413e-04);    // 1/7!
+    p = fma(p, r, 1.38888888888888894e-03);    // 1/6!
+    p = fma(p, r, 8.33333333333333322e-03);    // 1/5!
+    p = fma(p, r, 4.16666666666666644e-02);    // 1/4!
+    p = fma(p, r, 1.66666666666666657e-01);    // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+  }
 };
 template <> struct Real<float> {
   typedef f32x4 acc_t;
+  // phase A in difference form (k = b exp(-|x''-t''|^2/2), 3 ops per point and dimension):
+  // in fp32 the expansion's cancellation would cost ~4x accuracy on ill-conditioned real
+  // emulators, and fp32 VALU ops are half the price of fp64 ones
+  static constexpr bool kExpand = false;
   // v_mfma_f32_16x16x4_f32: row = 4 g + r
   __host__ __device__ static constexpr int own_sub(int r, int g) { return 4 * g + r; }
   __device__ static inline acc_t mfma(float a, float b, acc_t c) {
@@ -93,15 +124,16 @@ __host__ __device__ constexpr int frag_count_padded(int NB, int chunk) {
   return (frag_count(NB) + chunk - 1) / chunk * chunk;
 }
 
-// Row stride (in reals) of the LDS/global image of [x'_0 .. x'_{D-1}, alpha]: even, so
-// rows stay 16-byte aligned for f64.
-__host__ __device__ constexpr int row_stride(int D) { return (D + 1 + 3) & ~3; }
+// Row stride (in reals) of the LDS/global image of one training point,
+//   [x''_0 .. x''_{D-1}, alpha_i, h_i],   x'' = sqrt(e) (x - c),  h_i = ln b - |x''_i|^2 / 2,
+// rounded up to a multiple of 4 reals so rows stay 16-byte aligned in both precisions.
+__host__ __device__ constexpr int row_stride(int D) { return (D + 2 + 3) & ~3; }
 
 template <typename T>
 struct PredictArgs {
-  const T* xa;        // [16*NB][row_stride(D)]  pre-scaled inputs + alpha (zero padded)
+  const T* xa;        // [16*NB][row_stride(D)]  training rows [x'', alpha, h] (zero padded)
   const T* frags;     // [frag_count_padded(NB,kChunk)][64]  S' in fragment order
-  const T* sd;        // [D] sqrt(e_d)
+  const T* sd;        // [2*D] sqrt(e_d), then the centre c_d (training mean, input units)
   T b;                // e[D]
   const T* testing;   // [M][d_actual] row-major test inputs (device)
   T* mu;              // [M]
@@ -120,33 +152,58 @@ __device__ inline T xor_reduce_groups(T v) {
   return v;
 }
 
-// One chunk (kChunk fragments of 64 reals) global -> LDS with global_load_lds_dwordx4:
-// each wave-instruction moves 1 KiB to a wave-uniform LDS base + lane*16, so the linear
-// fragment order of the packed buffer is also the LDS order (no swizzle, and the 64-lane
-// ds_read_b64 / ds_read_b32 of a fragment is conflict-free).  Completion is covered by the
-// vmcnt(0) that __syncthreads() emits while an LDS-DMA is pending (guide section 5).
+// One chunk (kChunk fragments of 64 reals) global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4): each wave-instruction moves 1 KiB to a wave-uniform LDS base
+// (M0) + lane*16, so the linear fragment order of the packed buffer is also the LDS order
+// (no swizzle; the 64-lane ds_read_b64 / ds_read_b32 of a fragment is conflict-free).
+//
+// Written as inline asm on purpose: with the builtin, hipcc puts `s_waitcnt vmcnt(0)` in
+// front of the next ds_read (it cannot prove the DMA's LDS write does not alias it), which
+// serialises the copy with the MFMA work it is meant to hide under.  The contract for the
+// asm form (cdna_hip_programming.md 5.7): nothing reads the destination buffer until the
+// issuing wave has run dma_wait() and the workgroup has passed a barrier.  Compiler-placed
+// vmcnt waits stay safe: un-counted extra operations can only make them wait longer.
+// M0 is a reserved register the compiler never allocates and reloads before each of its
+// own uses (none in this kernel), so the asm sets it without listing it as a clobber.
 template <typename T>
 __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int lane) {
   constexpr int kBytes = kChunk * 64 * (int)sizeof(T);
   constexpr int kPerWave = kBytes / kWaves;       // bytes each wave moves
   constexpr int kIters = kPerWave / 1024;
   static_assert(kIters * 1024 * kWaves == kBytes, "chunk must be whole 1 KiB pieces per wave");
-  // wave-uniform SGPR base + 32-bit per-lane VGPR offset: the saddr form of the
-  // instruction, so no 64-bit per-lane addresses are kept (or hoisted and spilled)
+  static_assert(kIters == 4 || kIters == 2, "unexpected chunk size");
+  // wave-uniform SGPR source base, 32-bit per-lane VGPR offset (saddr form); the
+  // instruction's immediate offset applies to BOTH the global and the LDS address
   const char* s = reinterpret_cast<const char*>(src) + wave * kPerWave;
-  char* d = reinterpret_cast<char*>(dst) + wave * kPerWave;
-  unsigned voff = (unsigned)lane * 16u;
-  // opaque re-definition: keeps the (SGPR base + zext VGPR) add next to the instruction so
-  // instruction selection sees it, instead of a hoisted 64-bit per-lane pointer
-  asm volatile("" : "+v"(voff));
-  // the instruction's immediate offset applies to BOTH the global and the LDS address
-  static_for<kIters>([&](auto ic) {
-    constexpr int it = decltype(ic)::value;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(s + voff),
-        (__attribute__((address_space(3))) void*)d, 16, it * 1024, 0);
-  });
+  const unsigned lds = (unsigned)(uintptr_t)(
+      (__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(dst)) + wave * kPerWave);
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds);
+  const unsigned voff = (unsigned)lane * 16u;
+  if constexpr (kIters == 4) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072"
+        :
+        : "s"(m0v), "v"(voff), "s"(s)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024"
+        :
+        : "s"(m0v), "v"(voff), "s"(s)
+        : "memory");
+  }
 }
+// Retire this wave's outstanding LDS-DMA pieces; call right before the barrier that
+// publishes the chunk.
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T, int D, int NB>
 __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) {
@@ -167,9 +224,12 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
   const int g = lane >> 4;
 
   for (int i = tid; i < NP * DS; i += kThreads) s_xa[i] = p.xa[i];
-  T sd[D];
+  T sd[D], ctr[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) sd[d] = (d < p.d_actual) ? p.sd[d] : T(0);
+  for (int d = 0; d < D; ++d) {
+    sd[d] = (d < p.d_actual) ? p.sd[d] : T(0);
+    ctr[d] = (d < p.d_actual) ? p.sd[D + d] : T(0);
+  }
   const T b = p.b;
   __syncthreads();
 
@@ -183,10 +243,18 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
     stage_chunk<T>(p.frags, &s_fr[0][0], wave, lane);
 
     // ---------------- phase A: K_* tile, mean, gradient --------------------
+    // k_i = b exp(-|x''_i - t''|^2 / 2) = exp(h_i + g + x''_i . t''),  g = -|t''|^2 / 2:
+    // one fma per (training point, dimension) for the kernel row and one for the gradient
+    // sum  G_d = sum_i w_i x''_id,  deriv_d = sqrt(e_d) (G_d - t''_d mu).  Centring on the
+    // training mean c keeps |x''|, |t''| (hence the cancellation in h + g + x.t) small.
     T t[D];
+    T gm = T(0);
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-      t[d] = (d < p.d_actual) ? sd[d] * p.testing[mc * p.d_actual + d] : T(0);
+    for (int d = 0; d < D; ++d) {
+      t[d] = (d < p.d_actual) ? sd[d] * (p.testing[mc * p.d_actual + d] - ctr[d]) : T(0);
+      gm = fma(t[d], t[d], gm);
+    }
+    gm *= T(-0.5);
 
     T kv[4 * NB];
     T mu = T(0);
@@ -198,23 +266,36 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
       constexpr int q = decltype(qc)::value;
       const int i = own_index<T>(q >> 2, q & 3, g);
       const T* row = &s_xa[i * DS];
-      T dl[D];
-      T r2 = T(0);
+      T x[D];
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        dl[d] = row[d] - t[d];
-        r2 = fma(dl[d], dl[d], r2);
+      for (int d = 0; d < D; ++d) x[d] = row[d];
+      T k;
+      if constexpr (R::kExpand) {
+        T arg = row[D + 1] + gm;
+#pragma unroll
+        for (int d = 0; d < D; ++d) arg = fma(x[d], t[d], arg);
+        k = R::exp_(arg);
+      } else {
+        T r2 = T(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          x[d] -= t[d];
+          r2 = fma(x[d], x[d], r2);
+        }
+        k = b * R::exp_(T(-0.5) * r2);
       }
-      const T k = b * R::exp_(T(-0.5) * r2);
       kv[q] = k;
       const T w = k * row[D];
       mu += w;
 #pragma unroll
-      for (int d = 0; d < D; ++d) ga[d] = fma(w, dl[d], ga[d]);
+      for (int d = 0; d < D; ++d) ga[d] = fma(w, x[d], ga[d]);
     });
     mu = xor_reduce_groups(mu);
 #pragma unroll
-    for (int d = 0; d < D; ++d) ga[d] = xor_reduce_groups(ga[d]) * sd[d];
+    for (int d = 0; d < D; ++d) {
+      const T gsum = xor_reduce_groups(ga[d]);
+      ga[d] = sd[d] * (R::kExpand ? fma(-t[d], mu, gsum) : gsum);
+    }
 
     if (m < p.M) {
       if (g == 0) p.mu[m] = mu;
@@ -237,6 +318,7 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
       constexpr int J = pair_col(pair);
       constexpr int I = pair - J * (J + 1) / 2;
       if constexpr (fl == 0) {
+        dma_wait();       // this wave's pieces of chunk c have landed
         __syncthreads();  // chunk c visible; everyone finished reading chunk c-1
         if constexpr (c + 1 < NCH)
           stage_chunk<T>(p.frags + (c + 1) * kChunk * 64, &s_fr[(c + 1) & 1][0], wave, lane);

@@ -108,8 +108,9 @@ int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
                       void* d_mu, void* d_var, void* d_deriv, int64_t n_predict,
                       int deriv_layout);
 
-/* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  Buffers are
- * sized by gp_pack_sizes; used by the CPU tests to check the fragment layout. */
+/* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  xa and frags
+ * are sized by gp_pack_sizes; sd takes 2*kernel_d reals (sqrt(e_d), then the centre c_d);
+ * used by the CPU tests to check the fragment layout. */
 int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,
                   int64_t* xa_len, int64_t* frags_len);
 int gp_pack_model_f64(const double* expX, const double* inputs, const double* invQt,
