@@ -159,12 +159,30 @@ class GaussianProcess:
         return m
 
     # ------------------------------------------------------------------ Hessian
-    def hessian(self, testing):
-        """(nn, D, D) Hessian of the mean, numpy (reference :345-366; the reference has no
-        GPU version).  Written as the symmetric rank-N update it is:
-        H = sum_i w_i u_i u_i^T - diag(e) mu,  w = a * invQt,  u_i = e * (x_i - t)."""
+    def hessian(self, testing, is_gpu=False, precision=np.float64):
+        """(nn, D, D) Hessian of the mean (reference :345-366, which is numpy only and takes
+        just ``testing``).  ``is_gpu=True`` runs the fused HIP kernel through the C ABI
+        (``gp_hessian_f64/_f32``) and, like ``predict``, never falls back to the CPU.
+        ``is_gpu=False`` is the explicit numpy branch, written as the symmetric rank-N update
+        it is: H = sum_i w_i u_i u_i^T - diag(e) mu,  w = a * invQt,  u_i = e * (x_i - t)."""
         (nn, D) = testing.shape
         assert D == self.D
+        if is_gpu == True:  # noqa: E712
+            from . import _lib
+            dt = np.dtype(precision)
+            ctx = _lib.default_context(0)
+            fn = ctx.lib.gp_hessian_f64 if dt == np.float64 else ctx.lib.gp_hessian_f32
+            if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+                raise TypeError("precision must be float32 or float64")
+
+            def cast(a):
+                return np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=dt)
+            expX, inputs, invQt, t = (cast(np.exp(self.theta)), cast(self.inputs),
+                                      cast(self.invQt), cast(testing))
+            hess = np.zeros(nn * D * D, dtype=dt)
+            p = [a.ctypes.data_as(_lib.c_void_p) for a in (expX, inputs, invQt, t, hess)]
+            _lib.check(fn(ctx.h, *p, nn, self.inputs.shape[0], D, self.theta.size), "gp_hessian")
+            return hess.reshape(nn, D, D).astype(np.float64, copy=False)
         expX = np.exp(self.theta)
         s = np.sqrt(expX[:D])
         a = expX[D] * np.exp(-0.5 * dist.cdist(s * self.inputs, s * testing, "sqeuclidean"))

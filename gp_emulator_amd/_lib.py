@@ -39,6 +39,9 @@ SIGNATURES = {
     "gp_model_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5),
     "gp_predict_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_i64, c_int]),
+    "gp_hessian_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
+    "gp_hessian_f64": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
+    "gp_hessian_f32": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_pack_sizes": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                               ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "gp_pack_model_f64": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),
@@ -194,12 +197,16 @@ class Model:
         self.n_train, self.n_inputs = inputs.shape
         expX = np.ascontiguousarray(expX, dtype=self.dtype).ravel()
         invQt = np.ascontiguousarray(invQt, dtype=self.dtype).ravel()
-        invQ = np.ascontiguousarray(invQ, dtype=self.dtype)
-        if invQ.size != self.n_train ** 2 or invQt.size != self.n_train:
-            raise ValueError("invQ / invQt size does not match n_train")
+        if invQt.size != self.n_train:
+            raise ValueError("invQt size does not match n_train")
+        if invQ is not None:             # None: Hessian-only model (no variance operand)
+            invQ = np.ascontiguousarray(invQ, dtype=self.dtype)
+            if invQ.size != self.n_train ** 2:
+                raise ValueError("invQ size does not match n_train")
         fn = ctx.lib.gp_model_create_f64 if self.dtype == np.float64 else ctx.lib.gp_model_create_f32
         h = c_void_p()
-        check(fn(ctx.h, _ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ),
+        check(fn(ctx.h, _ptr(expX), _ptr(inputs), _ptr(invQt),
+                 _ptr(invQ) if invQ is not None else None,
                  self.n_train, self.n_inputs, expX.size, ctypes.byref(h)), "gp_model_create")
         self.h = h
 
@@ -239,6 +246,27 @@ class Model:
             for p in (d_t, d_mu, d_var, d_der):
                 self.ctx.free(p)
         return mu, var, deriv
+
+    def hessian_device(self, d_testing, d_hess, n_predict):
+        """Asynchronous Hessian launch; device pointers, hess is (n_predict, D, D)."""
+        check(self.ctx.lib.gp_hessian_device(self.ctx.h, self.h, d_testing, d_hess,
+                                             int(n_predict)), "gp_hessian_device")
+
+    def hessian(self, testing):
+        testing = np.ascontiguousarray(testing, dtype=self.dtype)
+        M, D = testing.shape
+        if D != self.n_inputs:
+            raise ValueError("testing has %d columns, model has %d inputs" % (D, self.n_inputs))
+        if M == 0:
+            return np.empty((0, D, D), self.dtype)
+        d_t = self.ctx.to_device(testing)
+        d_h = self.ctx.malloc(M * D * D * self.dtype.itemsize)
+        try:
+            self.hessian_device(d_t, d_h, M)
+            return self.ctx.to_host(d_h, (M, D, D), self.dtype)
+        finally:
+            self.ctx.free(d_t)
+            self.ctx.free(d_h)
 
     def close(self):
         if getattr(self, "h", None):

@@ -69,6 +69,9 @@ def build(force=False, jobs=None, verbose=True):
             tasks.append([HIPCC] + FLAGS + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
                                             "-DGP_NB=%d" % nb, "-c",
                                             os.path.join(CSRC, "gp_kernels_tu.hip"), "-o", obj])
+        obj = os.path.join(OBJ, "hess_%s.o" % tname)
+        tasks.append([HIPCC] + FLAGS + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
+                                        os.path.join(CSRC, "gp_hessian_tu.hip"), "-o", obj])
     abi_obj = os.path.join(OBJ, "gp_abi.o")
     tasks.append([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, "gp_abi.hip"), "-o", abi_obj])
     # biggest kernels first so the pool drains evenly

@@ -12,9 +12,12 @@
 #include <vector>
 
 #include "gp_dispatch.hpp"
+#include "gp_hessian_kernel.hpp"
 #include "gp_predict_kernel.hpp"
 
 namespace gpk {
+hipError_t launch_hessian_f32(int, const HessianArgs<float>&, int, hipStream_t);
+hipError_t launch_hessian_f64(int, const HessianArgs<double>&, int, hipStream_t);
 #define GP_DECL(nb)                                                                         \
   hipError_t launch_predict_f32_##nb(int, const PredictArgs<float>&, int, hipStream_t);     \
   hipError_t launch_predict_f64_##nb(int, const PredictArgs<double>&, int, hipStream_t);
@@ -99,7 +102,7 @@ static int pick_kernel(int n_train, int n_inputs, int* kd, int* knb) {
 template <typename T>
 static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* invQ, int N,
                       int D, int theta_size, T* xa, T* frags, T* sd, T* b) {
-  if (!expX || !inputs || !invQt || !invQ || !xa || !frags || !sd || !b)
+  if (!expX || !inputs || !invQt || !xa || !sd || !b || (invQ && !frags))
     return fail(GP_ERR_INVALID, "null pointer");
   if (N <= 0 || D <= 0) return fail(GP_ERR_INVALID, "n_train and n_inputs must be positive");
   if (theta_size < D + 1)
@@ -143,6 +146,7 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
   //   S'[i = 16 I + own_sub(s, l >> 4)][j = 16 J + (l & 15)]
   // with S'_IJ = M_IJ + M_JI^T for I < J and M_JJ on the diagonal, so that
   //   k^T M k = sum_J sum_{I<=J} k_I^T S'_IJ k_J        for ANY matrix M.
+  if (!invQ) return GP_OK;   // Hessian-only model: no variance operand
   const int nfp = gpk::frag_count_padded(knb, gpk::kChunk);
   std::memset(frags, 0, sizeof(T) * (size_t)nfp * 64);
   for (int J = 0; J < knb; ++J)
@@ -292,7 +296,7 @@ static int model_create(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   int64_t xa_len, fr_len;
   int rc = gp_pack_sizes(0, N, D, &kd, &knb, &xa_len, &fr_len);
   if (rc) return rc;
-  std::vector<T> xa(xa_len), fr(fr_len), sd(2 * kd);
+  std::vector<T> xa(xa_len), fr(invQ ? fr_len : 0), sd(2 * kd);
   T b;
   rc = pack_model<T>(expX, inputs, invQt, invQ, N, D, theta_size, xa.data(), fr.data(), sd.data(), &b);
   if (rc) return rc;
@@ -308,10 +312,10 @@ static int model_create(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   m->b = (double)b;
   m->d_xa = m->d_frags = m->d_sd = nullptr;
   hipError_t e = hipMalloc(&m->d_xa, sizeof(T) * xa_len);
-  if (e == hipSuccess) e = hipMalloc(&m->d_frags, sizeof(T) * fr_len);
+  if (e == hipSuccess && invQ) e = hipMalloc(&m->d_frags, sizeof(T) * fr_len);
   if (e == hipSuccess) e = hipMalloc(&m->d_sd, sizeof(T) * 2 * kd);
   if (e == hipSuccess) e = hipMemcpyAsync(m->d_xa, xa.data(), sizeof(T) * xa_len, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(m->d_frags, fr.data(), sizeof(T) * fr_len, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && invQ) e = hipMemcpyAsync(m->d_frags, fr.data(), sizeof(T) * fr_len, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(m->d_sd, sd.data(), sizeof(T) * 2 * kd, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host vectors die at return
   if (e != hipSuccess) {
@@ -343,6 +347,36 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   if (grid > groups) grid = groups;
   hipError_t e = launch<T>(m->kernel_nb, m->kernel_d, a, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(GP_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
+template <typename T>
+static hipError_t launch_hessian(int kd, const gpk::HessianArgs<T>& a, int grid, hipStream_t s);
+template <>
+hipError_t launch_hessian<float>(int kd, const gpk::HessianArgs<float>& a, int grid, hipStream_t s) {
+  return gpk::launch_hessian_f32(kd, a, grid, s);
+}
+template <>
+hipError_t launch_hessian<double>(int kd, const gpk::HessianArgs<double>& a, int grid, hipStream_t s) {
+  return gpk::launch_hessian_f64(kd, a, grid, s);
+}
+
+template <typename T>
+static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_hess, int64_t M) {
+  gpk::HessianArgs<T> a;
+  a.xa = (const T*)m->d_xa;
+  a.sd = (const T*)m->d_sd;
+  a.b = (T)m->b;
+  a.testing = (const T*)d_testing;
+  a.hess = (T*)d_hess;
+  a.M = M;
+  a.d_actual = m->n_inputs;
+  a.nb = (m->n_train + 15) / 16;     // the loop over training points is a run-time loop
+  const int64_t groups = (M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG;
+  int64_t grid = (int64_t)ctx->compute_units * 2;
+  if (grid > groups) grid = groups;
+  hipError_t e = launch_hessian<T>(m->kernel_d, a, (int)grid, ctx->stream);
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian kernel launch: %s", hipGetErrorString(e));
   return GP_OK;
 }
 
@@ -401,6 +435,38 @@ static int predict_wrap(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   return GP_OK;
 }
 
+// Host-pointer Hessian: constants + test rows up, one launch per slab, (M, D, D) down.
+template <typename T>
+static int hessian_host(gp_ctx* ctx, const T* expX, const T* inputs, const T* invQt,
+                        const T* testing, T* hess, int64_t M, int N, int D, int theta_size) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
+  if (M > 0 && (!testing || !hess)) return fail(GP_ERR_INVALID, "null pointer");
+  gp_model* m = nullptr;
+  int rc = model_create<T>(ctx, expX, inputs, invQt, (const T*)nullptr, N, D, theta_size, &m);
+  if (rc) return rc;
+  if (M == 0) { gp_model_destroy(m); return GP_OK; }
+  const int64_t slab = M < (int64_t)(1 << 20) ? M : (int64_t)(1 << 20);
+  const size_t per_row = sizeof(T) * (size_t)(D + D * D);
+  rc = ensure_scratch(ctx, per_row * (size_t)slab);
+  hipError_t e = hipSuccess;
+  for (int64_t s0 = 0; s0 < M && rc == GP_OK && e == hipSuccess; s0 += slab) {
+    const int64_t n = (M - s0 < slab) ? (M - s0) : slab;
+    T* d_t = (T*)ctx->scratch;
+    T* d_h = d_t + (size_t)n * D;
+    e = hipMemcpyAsync(d_t, testing + (size_t)s0 * D, sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) break;
+    rc = hessian_device<T>(ctx, m, d_t, d_h, n);
+    if (rc) break;
+    e = hipMemcpyAsync(hess + (size_t)s0 * D * D, d_h, sizeof(T) * (size_t)n * D * D, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  gp_model_destroy(m);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
 extern "C" {
 
 int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
@@ -441,6 +507,7 @@ int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
   if (deriv_layout != GP_DERIV_DMAJOR && deriv_layout != GP_DERIV_ROWMAJOR)
     return fail(GP_ERR_INVALID, "bad deriv_layout %d", deriv_layout);
   if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  if (!model->d_frags) return fail(GP_ERR_INVALID, "model was created without invQ: no variance operand");
   HIP_TRY(hipSetDevice(ctx->device));
   if (model->dtype == GP_F64)
     return predict_device<double>(ctx, model, d_testing, d_mu, d_var, d_deriv, n_predict, deriv_layout);
@@ -458,6 +525,28 @@ int gp_predict_wrap_f32(gp_ctx* ctx, const float* expX, const float* inputs, con
                         float* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
   return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
                              n_predict, n_train, n_inputs, theta_size);
+}
+
+int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing, void* d_hess,
+                      int64_t n_predict) {
+  if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
+  if (n_predict < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
+  if (n_predict == 0) return GP_OK;
+  if (!d_testing || !d_hess) return fail(GP_ERR_INVALID, "null device pointer");
+  if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (model->dtype == GP_F64) return hessian_device<double>(ctx, model, d_testing, d_hess, n_predict);
+  return hessian_device<float>(ctx, model, d_testing, d_hess, n_predict);
+}
+int gp_hessian_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
+                   const double* testing, double* hess, int64_t n_predict, int n_train,
+                   int n_inputs, int theta_size) {
+  return hessian_host<double>(ctx, expX, inputs, invQt, testing, hess, n_predict, n_train, n_inputs, theta_size);
+}
+int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
+                   const float* testing, float* hess, int64_t n_predict, int n_train,
+                   int n_inputs, int theta_size) {
+  return hessian_host<float>(ctx, expX, inputs, invQt, testing, hess, n_predict, n_train, n_inputs, theta_size);
 }
 
 int gp_malloc(gp_ctx* ctx, int64_t bytes, void** dptr) {

@@ -1,0 +1,122 @@
+// Hessian of the GP mean on gfx950: hess[m][d][d2] for every test row m.
+//
+// The reference has only a numpy version, gp_emulator/GaussianProcess.py:345-366, which
+// makes D^2 passes over an (N_test, N_train) array.  Here it is one fused pass: with
+// w_i = k_i alpha_i and delta_i = x''_i - t'' (sqrt(e)-scaled, centred coordinates)
+//
+//   hess[d][d2] = sd_d sd_d2 * sum_i w_i delta_id delta_id2  -  [d == d2] e_d * sum_i w_i
+//
+// i.e. a symmetric rank-N update per test row.  It is done on the VALU, not the matrix
+// core: fp64 MFMA and fp64 VALU issue at the same rate on MI355X (and share the pipe --
+// tools/mfma_f64_probe.hip), and only the VALU form can exploit the symmetry (D(D+1)/2
+// products instead of the 16x16 a matrix-core tile would spend), so it is ~2x cheaper.
+//
+// Lane layout as in the predict kernel: lane l works for test row (l & 15) and the quarter
+// (l >> 4) of the training points; the D(D+1)/2 partial sums live in registers (one wave
+// per SIMD: up to 136 fp64 accumulators), are summed over the four lane groups at the end,
+// and each lane group writes a quarter of the rows of the (D, D) block.  The loop over
+// training points is a real loop (nothing is indexed by it), so the code stays small.
+#pragma once
+#include "gp_predict_kernel.hpp"
+
+namespace gpk {
+
+template <typename T>
+struct HessianArgs {
+  const T* xa;        // [16*nb][row_stride(D)] training rows [x'', alpha, h]
+  const T* sd;        // [2*D] sqrt(e_d), then the centre c_d
+  T b;                // e[D]
+  const T* testing;   // [M][d_actual]
+  T* hess;            // [M][d_actual][d_actual]
+  long long M;
+  int d_actual;
+  int nb;             // 16-row blocks of training points
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(kThreads, 1) void hessian_kernel(HessianArgs<T> p) {
+  typedef Real<T> R;
+  constexpr int DS = row_stride(D);
+  constexpr int NPAIR = D * (D + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  T* s_xa = reinterpret_cast<T*>(s_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ml = lane & 15;
+  const int g = lane >> 4;
+  const int np = 16 * p.nb;
+
+  for (int i = tid; i < np * DS; i += kThreads) s_xa[i] = p.xa[i];
+  // sqrt(e_d) and the centre stay in LDS (broadcast reads), not in registers: the
+  // D(D+1)/2 accumulators need the register file
+  T* s_sd = s_xa + np * DS;
+  if (tid < 2 * D) s_sd[tid] = ((tid % D) < p.d_actual) ? p.sd[tid] : T(0);
+  const T b = p.b;
+  __syncthreads();
+
+  const long long n_groups = (p.M + kRowsPerWG - 1) / kRowsPerWG;
+  for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const long long m = grp * kRowsPerWG + wave * kTile + ml;
+    const long long mc = m < p.M ? m : p.M - 1;
+    T t[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      t[d] = (d < p.d_actual) ? s_sd[d] * (p.testing[mc * p.d_actual + d] - s_sd[D + d]) : T(0);
+
+    T acc[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) acc[q] = T(0);
+    T mu = T(0);
+
+    // one training point per iteration, NOT unrolled: unrolling lets the scheduler keep
+    // several points' delta vectors live on top of the D(D+1)/2 accumulators and spill
+#pragma unroll 1
+    for (int qq = 0; qq < 4 * p.nb; ++qq) {
+      {
+        const int i = 16 * (qq >> 2) + R::own_sub(qq & 3, g);
+        const T* row = &s_xa[i * DS];
+        T dl[D];
+        T r2 = T(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          dl[d] = row[d] - t[d];
+          r2 = fma(dl[d], dl[d], r2);
+        }
+        const T w = b * R::exp_(T(-0.5) * r2) * row[D];
+        mu += w;
+        int q = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const T wd = w * dl[d];
+#pragma unroll
+          for (int d2 = d; d2 < D; ++d2) {
+            acc[q] = fma(wd, dl[d2], acc[q]);
+            ++q;
+          }
+        }
+      }
+    }
+    mu = xor_reduce_groups(mu);
+    // reduce over the four lane groups; lane group g then stores rows d == g (mod 4)
+    T* out = p.hess + (m < p.M ? m : 0) * (long long)p.d_actual * p.d_actual;
+    int q = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int d2 = d; d2 < D; ++d2) {
+        T v = xor_reduce_groups(acc[q]) * (s_sd[d] * s_sd[d2]);
+        if (d2 == d) v = fma(-(s_sd[d] * s_sd[d]), mu, v);
+        ++q;
+        if (m < p.M && d < p.d_actual && d2 < p.d_actual) {
+          // element (d, d2) by group d & 3, its mirror (d2, d) by group d2 & 3
+          if ((d & 3) == g) out[d * p.d_actual + d2] = v;
+          if (d2 != d && (d2 & 3) == g) out[d2 * p.d_actual + d] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace gpk

@@ -90,7 +90,8 @@ int gp_predict_wrap_f32(gp_ctx* ctx, const float* expX, const float* inputs,
  * gp_model_create_*: pack (host side, in double) and upload the per-emulator constants the
  * reference re-uploads for every block (predict.cu:17-33): sqrt(e)-scaled training inputs
  * + invQt, and invQ folded to S' in matrix-core fragment order.  compute dtype = the
- * function's dtype. */
+ * function's dtype.  invQ may be NULL: the model then serves gp_hessian_device only and
+ * gp_predict_device on it fails with GP_ERR_INVALID. */
 int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs,
                         const double* invQt, const double* invQ,
                         int n_train, int n_inputs, int theta_size, gp_model** out);
@@ -107,6 +108,20 @@ int gp_model_info(const gp_model* model, int* dtype, int* n_train, int* n_inputs
 int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
                       void* d_mu, void* d_var, void* d_deriv, int64_t n_predict,
                       int deriv_layout);
+
+/* ---- Hessian of the mean ------------------------------------------------------------------
+ * Replaces GaussianProcess.hessian (gp_emulator/GaussianProcess.py:345-366; the reference
+ * has NO native version of it).  hess is (n_predict, n_inputs, n_inputs) row-major.
+ * gp_hessian_device: device pointers, asynchronous on the context's stream.
+ * gp_hessian_f64/_f32: host pointers in and out (invQ is not needed by the Hessian). */
+int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
+                      void* d_hess, int64_t n_predict);
+int gp_hessian_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
+                   const double* testing, double* hess,
+                   int64_t n_predict, int n_train, int n_inputs, int theta_size);
+int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
+                   const float* testing, float* hess,
+                   int64_t n_predict, int n_train, int n_inputs, int theta_size);
 
 /* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  xa and frags
  * are sized by gp_pack_sizes; sd takes 2*kernel_d reals (sqrt(e_d), then the centre c_d);

@@ -168,3 +168,58 @@ def test_full_size_properties_c2(gpu_lib):
     mu4, var4, der4 = m1.predict(testing[:200000][perm])
     assert np.array_equal(mu4, mu[:200000][perm]) and np.array_equal(var4, var[:200000][perm])
     assert np.array_equal(der4, der[:200000][perm])
+
+
+# ---------------------------------------------------------------------------------------
+# Hessian (reference: numpy only, GaussianProcess.py:345-366; no reference test exists, so
+# parity is pinned by the reference-generated goldens and by finite differences)
+# ---------------------------------------------------------------------------------------
+HESS_CASES = [n for n in SYNTHETIC_CASES if n not in ("bench_n250_d10", "c4_n300_d11")]
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("name", HESS_CASES)
+def test_hessian_matches_golden(gpu_lib, name, precision):
+    g = synthetic_case(name)
+    gp = make_gp(g)
+    mh = g["hess"].shape[0]
+    h = gp.hessian(g["testing"][:mh], is_gpu=True, precision=precision)
+    assert h.shape == g["hess"].shape
+    e = gp_oracle.maxnorm_err(g["hess"], h)
+    assert e <= TOL[precision], (name, e)
+    assert np.array_equal(h, np.transpose(h, (0, 2, 1)))      # exactly symmetric by construction
+
+
+def test_hessian_real_emulator(gpu_lib):
+    g = load_golden("prosail_pc0")
+    gp = make_gp(g)
+    h = gp.hessian(g["testing"][:64], is_gpu=True)
+    assert gp_oracle.maxnorm_err(g["hess"], h) <= 1e-10
+
+
+def test_hessian_is_derivative_of_gpu_gradient(gpu_lib):
+    """Central differences of the GPU gradient reproduce the GPU Hessian."""
+    g = synthetic_case("c5_n300_d16")
+    gp = make_gp(g)
+    x = g["testing"][:32]
+    H = gp.hessian(x, is_gpu=True)
+    m = gp.gpu_model(np.float64)
+    hstep = 1e-5
+    for d in range(0, 16, 5):
+        xp, xm = x.copy(), x.copy()
+        xp[:, d] += hstep
+        xm[:, d] -= hstep
+        fd = (m.predict(xp)[2] - m.predict(xm)[2]) / (2 * hstep)
+        assert np.allclose(fd, H[:, d, :], rtol=2e-6, atol=2e-5 * np.max(np.abs(H)))
+
+
+def test_hessian_ragged_and_device_resident(gpu_lib):
+    g = synthetic_case("c2_n250_d11")
+    ctx = _lib.default_context(0)
+    m = _lib.Model(ctx, np.exp(g["theta"]), g["inputs"], g["invQt"], None)   # no invQ needed
+    for M in (1, 17, 65, 256):
+        h = m.hessian(g["testing"][:M])
+        assert gp_oracle.maxnorm_err(g["hess"][:M], h) <= 1e-10 * max(
+            1.0, np.max(np.abs(g["hess"])) / np.max(np.abs(g["hess"][:M])))
+    with pytest.raises(_lib.GpuPredictError):
+        m.predict(g["testing"][:4])      # model without invQ cannot give a variance
