@@ -35,6 +35,9 @@ SIGNATURES = {
     "gp_predict_wrap_f32": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
     "gp_model_create_f64": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_model_create_f32": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
+    "gp_batch_create_f64": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
+    "gp_batch_create_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
+    "gp_model_emulators": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "gp_model_destroy": (c_int, [c_void_p]),
     "gp_model_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5),
     "gp_predict_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -276,6 +279,61 @@ class Model:
     __del__ = close
 
 
+class BatchModel(Model):
+    """E emulators on the SAME training inputs (per-band pattern,
+    tests/test_perband_emulator.py:22-37), predicted over shared test rows in ONE launch.
+
+    expX (E, D+2), inputs (N, D), invQt (E, N), invQ (E, N, N).
+    ``predict`` returns mu (E, M), var (E, M), deriv (E, M, D).
+    """
+
+    def __init__(self, ctx, expX, inputs, invQt, invQ, precision=np.float64):
+        self.ctx = ctx
+        self.dtype = np.dtype(precision)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("precision must be float32 or float64, got %r" % (precision,))
+        inputs = np.ascontiguousarray(inputs, dtype=self.dtype)
+        self.n_train, self.n_inputs = inputs.shape
+        expX = np.ascontiguousarray(expX, dtype=self.dtype)
+        if expX.ndim != 2:
+            raise ValueError("expX must be (n_emulators, theta_size)")
+        self.n_emulators = E = expX.shape[0]
+        invQt = np.ascontiguousarray(invQt, dtype=self.dtype)
+        invQ = np.ascontiguousarray(invQ, dtype=self.dtype)
+        if invQt.shape != (E, self.n_train) or invQ.shape != (E, self.n_train, self.n_train):
+            raise ValueError("invQt must be (E, N) and invQ (E, N, N)")
+        fn = ctx.lib.gp_batch_create_f64 if self.dtype == np.float64 else ctx.lib.gp_batch_create_f32
+        h = c_void_p()
+        check(fn(ctx.h, E, _ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ),
+                 self.n_train, self.n_inputs, expX.shape[1], ctypes.byref(h)), "gp_batch_create")
+        self.h = h
+
+    def predict(self, testing, deriv_layout=GP_DERIV_ROWMAJOR):
+        testing = np.ascontiguousarray(testing, dtype=self.dtype)
+        M, D = testing.shape
+        E = self.n_emulators
+        if D != self.n_inputs:
+            raise ValueError("testing has %d columns, model has %d inputs" % (D, self.n_inputs))
+        isz = self.dtype.itemsize
+        d_t = self.ctx.to_device(testing)
+        d_mu = self.ctx.malloc(max(1, E * M * isz))
+        d_var = self.ctx.malloc(max(1, E * M * isz))
+        d_der = self.ctx.malloc(max(1, E * M * D * isz))
+        try:
+            self.predict_device(d_t, d_mu, d_var, d_der, M, deriv_layout)
+            mu = self.ctx.to_host(d_mu, (E, M), self.dtype)
+            var = self.ctx.to_host(d_var, (E, M), self.dtype)
+            shape = (E, M, D) if deriv_layout == GP_DERIV_ROWMAJOR else (E, D, M)
+            deriv = self.ctx.to_host(d_der, shape, self.dtype)
+        finally:
+            for p in (d_t, d_mu, d_var, d_der):
+                self.ctx.free(p)
+        return mu, var, deriv
+
+    def hessian(self, testing):
+        raise GpuPredictError("hessian is per emulator; build a Model for the emulator wanted")
+
+
 def pack_model(expX, inputs, invQt, invQ, precision=np.float64):
     """Host-only packing (no GPU): returns dict(xa, frags, sd, b, kernel_d, kernel_nb)."""
     lib = load()
@@ -290,12 +348,12 @@ def pack_model(expX, inputs, invQt, invQ, precision=np.float64):
                             ctypes.byref(knb), ctypes.byref(xl), ctypes.byref(fl)), "gp_pack_sizes")
     xa = np.zeros(xl.value, dt)
     fr = np.zeros(fl.value, dt)
-    sd = np.zeros(2 * kd.value, dt)
+    sd = np.zeros(2 * kd.value + 1, dt)
     b = np.zeros(1, dt)
     fn = lib.gp_pack_model_f64 if dt == np.float64 else lib.gp_pack_model_f32
     check(fn(_ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ), N, D, expX.size,
              _ptr(xa), _ptr(fr), _ptr(sd), _ptr(b)), "gp_pack_model")
-    return dict(xa=xa, frags=fr, sd=sd[:kd.value], centre=sd[kd.value:], b=b[0],
+    return dict(xa=xa, frags=fr, sd=sd[:kd.value], centre=sd[kd.value:2 * kd.value], b=b[0],
                 kernel_d=kd.value, kernel_nb=knb.value)
 
 

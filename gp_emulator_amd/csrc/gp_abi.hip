@@ -60,10 +60,11 @@ struct gp_model {
   int dtype;
   int n_train, n_inputs;
   int kernel_d, kernel_nb;
+  int n_emulators;                         // > 1: batched emulators sharing inputs/test rows
+  long long xa_stride, frags_stride, sd_stride;   // elements between emulators
   void* d_xa;
   void* d_frags;
   void* d_sd;
-  double b;
 };
 
 struct gp_event {
@@ -129,6 +130,7 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
     sd[kd + d] = (T)ctr[d];
   }
   *b = expX[D];
+  sd[2 * kd] = expX[D];
   const double lnb = std::log((double)expX[D]);
   std::memset(xa, 0, sizeof(T) * (size_t)NP * DS);
   for (int i = 0; i < N; ++i) {
@@ -287,19 +289,20 @@ int gp_pack_model_f32(const float* expX, const float* inputs, const float* invQt
 
 }  // extern "C"
 
+// Pack and upload E emulators that share the training inputs (E = 1: the plain case).
+// expX is [E][theta_size], invQt [E][N], invQ [E][N][N] (or null: Hessian-only model).
 template <typename T>
-static int model_create(gp_ctx* ctx, const T* expX, const T* inputs, const T* invQt,
+static int model_create(gp_ctx* ctx, int E, const T* expX, const T* inputs, const T* invQt,
                         const T* invQ, int N, int D, int theta_size, gp_model** out) {
   if (!ctx || !out) return fail(GP_ERR_INVALID, "null context or output");
   *out = nullptr;
+  if (E <= 0) return fail(GP_ERR_INVALID, "n_emulators must be positive");
   int kd, knb;
   int64_t xa_len, fr_len;
   int rc = gp_pack_sizes(0, N, D, &kd, &knb, &xa_len, &fr_len);
   if (rc) return rc;
-  std::vector<T> xa(xa_len), fr(invQ ? fr_len : 0), sd(2 * kd);
-  T b;
-  rc = pack_model<T>(expX, inputs, invQt, invQ, N, D, theta_size, xa.data(), fr.data(), sd.data(), &b);
-  if (rc) return rc;
+  const int64_t sd_len = 2 * kd + 1;
+  if (!invQ) fr_len = 0;
   HIP_TRY(hipSetDevice(ctx->device));
   gp_model* m = new (std::nothrow) gp_model();
   if (!m) return fail(GP_ERR_INVALID, "out of host memory");
@@ -309,15 +312,30 @@ static int model_create(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   m->n_inputs = D;
   m->kernel_d = kd;
   m->kernel_nb = knb;
-  m->b = (double)b;
+  m->n_emulators = E;
+  m->xa_stride = xa_len;
+  m->frags_stride = fr_len;
+  m->sd_stride = sd_len;
   m->d_xa = m->d_frags = m->d_sd = nullptr;
-  hipError_t e = hipMalloc(&m->d_xa, sizeof(T) * xa_len);
-  if (e == hipSuccess && invQ) e = hipMalloc(&m->d_frags, sizeof(T) * fr_len);
-  if (e == hipSuccess) e = hipMalloc(&m->d_sd, sizeof(T) * 2 * kd);
-  if (e == hipSuccess) e = hipMemcpyAsync(m->d_xa, xa.data(), sizeof(T) * xa_len, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && invQ) e = hipMemcpyAsync(m->d_frags, fr.data(), sizeof(T) * fr_len, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(m->d_sd, sd.data(), sizeof(T) * 2 * kd, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host vectors die at return
+  hipError_t e = hipMalloc(&m->d_xa, sizeof(T) * xa_len * E);
+  if (e == hipSuccess && invQ) e = hipMalloc(&m->d_frags, sizeof(T) * fr_len * E);
+  if (e == hipSuccess) e = hipMalloc(&m->d_sd, sizeof(T) * sd_len * E);
+  // pack one emulator at a time into a bounded host staging buffer, copy, repeat
+  std::vector<T> xa(xa_len), fr(fr_len), sd(sd_len);
+  for (int k = 0; k < E && e == hipSuccess && rc == GP_OK; ++k) {
+    T b;
+    rc = pack_model<T>(expX + (size_t)k * theta_size, inputs, invQt + (size_t)k * N,
+                       invQ ? invQ + (size_t)k * N * N : nullptr, N, D, theta_size,
+                       xa.data(), invQ ? fr.data() : nullptr, sd.data(), &b);
+    if (rc) break;
+    e = hipMemcpyAsync((T*)m->d_xa + (size_t)k * xa_len, xa.data(), sizeof(T) * xa_len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && invQ)
+      e = hipMemcpyAsync((T*)m->d_frags + (size_t)k * fr_len, fr.data(), sizeof(T) * fr_len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync((T*)m->d_sd + (size_t)k * sd_len, sd.data(), sizeof(T) * sd_len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // staging buffers are reused
+  }
+  if (rc) { gp_model_destroy(m); return rc; }
   if (e != hipSuccess) {
     gp_model_destroy(m);
     return fail(GP_ERR_HIP, "model upload: %s", hipGetErrorString(e));
@@ -333,7 +351,6 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.xa = (const T*)m->d_xa;
   a.frags = (const T*)m->d_frags;
   a.sd = (const T*)m->d_sd;
-  a.b = (T)m->b;
   a.testing = (const T*)d_testing;
   a.mu = (T*)d_mu;
   a.var = (T*)d_var;
@@ -341,7 +358,13 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.M = M;
   a.d_actual = m->n_inputs;
   a.deriv_row_major = layout == GP_DERIV_ROWMAJOR;
-  const int64_t groups = (M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG;
+  a.n_emulators = m->n_emulators;
+  a.xa_stride = m->xa_stride;
+  a.frags_stride = m->frags_stride;
+  a.sd_stride = m->sd_stride;
+  const int64_t groups = (M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG * m->n_emulators;
+  if ((M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG > 0x7fffffffLL)
+    return fail(GP_ERR_INVALID, "n_predict too large for one launch");
   // persistent grid: 2 workgroups per CU (the kernel's occupancy), grid-stride over groups
   int64_t grid = (int64_t)ctx->compute_units * 2;
   if (grid > groups) grid = groups;
@@ -366,7 +389,6 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   gpk::HessianArgs<T> a;
   a.xa = (const T*)m->d_xa;
   a.sd = (const T*)m->d_sd;
-  a.b = (T)m->b;
   a.testing = (const T*)d_testing;
   a.hess = (T*)d_hess;
   a.M = M;
@@ -403,7 +425,7 @@ static int predict_wrap(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
   if (M > 0 && (!testing || !result || !error || !deriv)) return fail(GP_ERR_INVALID, "null pointer");
   gp_model* m = nullptr;
-  int rc = model_create<T>(ctx, expX, inputs, invQt, invQ, N, D, theta_size, &m);
+  int rc = model_create<T>(ctx, 1, expX, inputs, invQt, invQ, N, D, theta_size, &m);
   if (rc) return rc;
   if (M == 0) { gp_model_destroy(m); return GP_OK; }
   const int64_t slab = M < (int64_t)(1 << 22) ? M : (int64_t)(1 << 22);  // rows per slab
@@ -443,7 +465,7 @@ static int hessian_host(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
   if (M > 0 && (!testing || !hess)) return fail(GP_ERR_INVALID, "null pointer");
   gp_model* m = nullptr;
-  int rc = model_create<T>(ctx, expX, inputs, invQt, (const T*)nullptr, N, D, theta_size, &m);
+  int rc = model_create<T>(ctx, 1, expX, inputs, invQt, (const T*)nullptr, N, D, theta_size, &m);
   if (rc) return rc;
   if (M == 0) { gp_model_destroy(m); return GP_OK; }
   const int64_t slab = M < (int64_t)(1 << 20) ? M : (int64_t)(1 << 20);
@@ -471,11 +493,26 @@ extern "C" {
 
 int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                         const double* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
-  return model_create<double>(ctx, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return model_create<double>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+}
+int gp_batch_create_f64(gp_ctx* ctx, int n_emulators, const double* expX, const double* inputs,
+                        const double* invQt, const double* invQ, int n_train, int n_inputs,
+                        int theta_size, gp_model** out) {
+  return model_create<double>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+}
+int gp_batch_create_f32(gp_ctx* ctx, int n_emulators, const float* expX, const float* inputs,
+                        const float* invQt, const float* invQ, int n_train, int n_inputs,
+                        int theta_size, gp_model** out) {
+  return model_create<float>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+}
+int gp_model_emulators(const gp_model* m, int* n_emulators) {
+  if (!m || !n_emulators) return fail(GP_ERR_INVALID, "null pointer");
+  *n_emulators = m->n_emulators;
+  return GP_OK;
 }
 int gp_model_create_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
                         const float* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
-  return model_create<float>(ctx, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return model_create<float>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
 }
 
 int gp_model_destroy(gp_model* m) {
@@ -534,6 +571,7 @@ int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
   if (n_predict == 0) return GP_OK;
   if (!d_testing || !d_hess) return fail(GP_ERR_INVALID, "null device pointer");
   if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  if (model->n_emulators != 1) return fail(GP_ERR_INVALID, "hessian is per emulator: batch of %d given", model->n_emulators);
   HIP_TRY(hipSetDevice(ctx->device));
   if (model->dtype == GP_F64) return hessian_device<double>(ctx, model, d_testing, d_hess, n_predict);
   return hessian_device<float>(ctx, model, d_testing, d_hess, n_predict);

@@ -24,8 +24,7 @@ namespace gpk {
 template <typename T>
 struct HessianArgs {
   const T* xa;        // [16*nb][row_stride(D)] training rows [x'', alpha, h]
-  const T* sd;        // [2*D] sqrt(e_d), then the centre c_d
-  T b;                // e[D]
+  const T* sd;        // [2*D + 1] sqrt(e_d), the centre c_d, b = e[D]
   const T* testing;   // [M][d_actual]
   T* hess;            // [M][d_actual][d_actual]
   long long M;
@@ -53,7 +52,7 @@ __global__ __launch_bounds__(kThreads, 1) void hessian_kernel(HessianArgs<T> p) 
   // D(D+1)/2 accumulators need the register file
   T* s_sd = s_xa + np * DS;
   if (tid < 2 * D) s_sd[tid] = ((tid % D) < p.d_actual) ? p.sd[tid] : T(0);
-  const T b = p.b;
+  const T b = p.sd[2 * D];
   __syncthreads();
 
   const long long n_groups = (p.M + kRowsPerWG - 1) / kRowsPerWG;

@@ -133,8 +133,7 @@ template <typename T>
 struct PredictArgs {
   const T* xa;        // [16*NB][row_stride(D)]  training rows [x'', alpha, h] (zero padded)
   const T* frags;     // [frag_count_padded(NB,kChunk)][64]  S' in fragment order
-  const T* sd;        // [2*D] sqrt(e_d), then the centre c_d (training mean, input units)
-  T b;                // e[D]
+  const T* sd;        // [2*D + 1] sqrt(e_d), the centre c_d (training mean, input units), b = e[D]
   const T* testing;   // [M][d_actual] row-major test inputs (device)
   T* mu;              // [M]
   T* var;             // [M]
@@ -142,6 +141,12 @@ struct PredictArgs {
   long long M;
   int d_actual;       // D of the caller (<= template D; extra template dims are zero)
   int deriv_row_major;
+  // Batched emulators (per-band pattern, tests/test_perband_emulator.py:22-37): E emulators
+  // share the test rows; emulator e has its constants at xa + e*xa_stride,
+  // frags + e*frags_stride, sd + e*sd_stride and its outputs at mu + e*M, var + e*M,
+  // deriv + e*M*d_actual.  n_emulators = 1 is the plain single-emulator call.
+  int n_emulators;
+  long long xa_stride, frags_stride, sd_stride;
 };
 
 template <typename T>
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
 
   __shared__ __attribute__((aligned(16))) T s_xa[NP * DS];
   __shared__ __attribute__((aligned(16))) T s_fr[2][kChunk * 64];
+  __shared__ T s_sd[2 * D + 1];   // sqrt(e_d), centre c_d, b: broadcast reads, no registers
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -223,24 +229,34 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
   const int ml = lane & 15;
   const int g = lane >> 4;
 
-  for (int i = tid; i < NP * DS; i += kThreads) s_xa[i] = p.xa[i];
-  T sd[D], ctr[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    sd[d] = (d < p.d_actual) ? p.sd[d] : T(0);
-    ctr[d] = (d < p.d_actual) ? p.sd[D + d] : T(0);
-  }
-  const T b = p.b;
-  __syncthreads();
-
-  const long long n_groups = (p.M + kRowsPerWG - 1) / kRowsPerWG;
-  for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const long long m = grp * kRowsPerWG + wave * kTile + ml;
+  // Work items are (emulator, group of 64 test rows), emulator-major, dealt round-robin to
+  // the persistent workgroups: at any moment the whole chip works on one or two emulators,
+  // so each XCD's L2 pulls an emulator's S' from HBM once and serves every CU from it.
+  // (e, grp) are advanced with scalar adds/compares only, so they stay in SGPRs.
+  const int n_groups = (int)((p.M + kRowsPerWG - 1) / kRowsPerWG);
+  int e = 0, cur_e = -1;
+  int grp = blockIdx.x;
+  while (grp >= n_groups && e < p.n_emulators) { grp -= n_groups; ++e; }
+  for (; e < p.n_emulators;) {
+    if (e != cur_e) {   // (re)load this emulator's training rows and scalars
+      cur_e = e;
+      __syncthreads();  // everyone is done with the previous emulator's rows
+      const T* xa = p.xa + e * p.xa_stride;
+      for (int i = tid; i < NP * DS; i += kThreads) s_xa[i] = xa[i];
+      const T* sdp = p.sd + e * p.sd_stride;
+      if (tid < 2 * D + 1) s_sd[tid] = (tid == 2 * D || (tid % D) < p.d_actual) ? sdp[tid] : T(0);
+    }
+    const T* frags = p.frags + e * p.frags_stride;
+    T* o_mu = p.mu + e * p.M;
+    T* o_var = p.var + e * p.M;
+    T* o_der = p.deriv + e * p.M * p.d_actual;
+    const long long m = (long long)grp * kRowsPerWG + wave * kTile + ml;
     const long long mc = m < p.M ? m : p.M - 1;
 
     // chunk 0 of S' goes L2 -> LDS by LDS-DMA now and lands under phase A
-    __syncthreads();  // previous group's readers of s_fr[0] are done
-    stage_chunk<T>(p.frags, &s_fr[0][0], wave, lane);
+    __syncthreads();  // previous item's readers of s_fr[0] are done; new rows visible
+    stage_chunk<T>(frags, &s_fr[0][0], wave, lane);
+    const T b = s_sd[2 * D];
 
     // ---------------- phase A: K_* tile, mean, gradient --------------------
     // k_i = b exp(-|x''_i - t''|^2 / 2) = exp(h_i + g + x''_i . t''),  g = -|t''|^2 / 2:
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
     T gm = T(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      t[d] = (d < p.d_actual) ? sd[d] * (p.testing[mc * p.d_actual + d] - ctr[d]) : T(0);
+      t[d] = (d < p.d_actual) ? s_sd[d] * (p.testing[mc * p.d_actual + d] - s_sd[D + d]) : T(0);
       gm = fma(t[d], t[d], gm);
     }
     gm *= T(-0.5);
@@ -294,16 +310,16 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const T gsum = xor_reduce_groups(ga[d]);
-      ga[d] = sd[d] * (R::kExpand ? fma(-t[d], mu, gsum) : gsum);
+      ga[d] = s_sd[d] * (R::kExpand ? fma(-t[d], mu, gsum) : gsum);
     }
 
     if (m < p.M) {
-      if (g == 0) p.mu[m] = mu;
+      if (g == 0) o_mu[m] = mu;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if ((d & 3) == g && d < p.d_actual) {
-          if (p.deriv_row_major) p.deriv[m * p.d_actual + d] = ga[d];
-          else p.deriv[(long long)d * p.M + m] = ga[d];
+          if (p.deriv_row_major) o_der[m * p.d_actual + d] = ga[d];
+          else o_der[(long long)d * p.M + m] = ga[d];
         }
       }
     }
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
         dma_wait();       // this wave's pieces of chunk c have landed
         __syncthreads();  // chunk c visible; everyone finished reading chunk c-1
         if constexpr (c + 1 < NCH)
-          stage_chunk<T>(p.frags + (c + 1) * kChunk * 64, &s_fr[(c + 1) & 1][0], wave, lane);
+          stage_chunk<T>(frags + (c + 1) * kChunk * 64, &s_fr[(c + 1) & 1][0], wave, lane);
       }
       if constexpr (I == 0 && s == 0) acc = acc_t{T(0), T(0), T(0), T(0)};
       acc = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc);
@@ -331,7 +347,10 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
       }
     });
     vacc = xor_reduce_groups(vacc);
-    if (m < p.M && g == 1) p.var[m] = b - vacc;
+    if (m < p.M && g == 1) o_var[m] = b - vacc;
+
+    grp += gridDim.x;
+    while (grp >= n_groups && e < p.n_emulators) { grp -= n_groups; ++e; }
   }
 }
 

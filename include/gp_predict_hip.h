@@ -98,6 +98,20 @@ int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs,
 int gp_model_create_f32(gp_ctx* ctx, const float* expX, const float* inputs,
                         const float* invQt, const float* invQ,
                         int n_train, int n_inputs, int theta_size, gp_model** out);
+/* Batched emulators: the per-band pattern of tests/test_perband_emulator.py:22-37 (one
+ * GaussianProcess per band, all on the SAME training inputs, each with its own theta,
+ * invQ, invQt), which the reference can only run as a Python loop over predict_wrap.
+ *   expX [E*theta_size], inputs [n_train*n_inputs] (shared), invQt [E*n_train],
+ *   invQ [E*n_train*n_train].
+ * gp_predict_device on such a model runs ALL emulators over the shared test rows in one
+ * launch; outputs are emulator-major: mu [E][M], var [E][M], deriv [E][M*D]. */
+int gp_batch_create_f64(gp_ctx* ctx, int n_emulators, const double* expX, const double* inputs,
+                        const double* invQt, const double* invQ,
+                        int n_train, int n_inputs, int theta_size, gp_model** out);
+int gp_batch_create_f32(gp_ctx* ctx, int n_emulators, const float* expX, const float* inputs,
+                        const float* invQt, const float* invQ,
+                        int n_train, int n_inputs, int theta_size, gp_model** out);
+int gp_model_emulators(const gp_model* model, int* n_emulators);
 int gp_model_destroy(gp_model* model);
 int gp_model_info(const gp_model* model, int* dtype, int* n_train, int* n_inputs,
                   int* kernel_d, int* kernel_nb);
@@ -124,7 +138,7 @@ int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const fl
                    int64_t n_predict, int n_train, int n_inputs, int theta_size);
 
 /* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  xa and frags
- * are sized by gp_pack_sizes; sd takes 2*kernel_d reals (sqrt(e_d), then the centre c_d);
+ * are sized by gp_pack_sizes; sd takes 2*kernel_d + 1 reals (sqrt(e_d), the centre c_d, b);
  * used by the CPU tests to check the fragment layout. */
 int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,
                   int64_t* xa_len, int64_t* frags_len);

@@ -223,3 +223,41 @@ def test_hessian_ragged_and_device_resident(gpu_lib):
             1.0, np.max(np.abs(g["hess"])) / np.max(np.abs(g["hess"][:M])))
     with pytest.raises(_lib.GpuPredictError):
         m.predict(g["testing"][:4])      # model without invQ cannot give a variance
+
+
+# ---------------------------------------------------------------------------------------
+# batched emulators (per-band pattern, tests/test_perband_emulator.py:22-37)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_batched_emulators_match_per_emulator_oracle(gpu_lib, precision):
+    """E emulators on shared inputs / shared test rows, own theta, invQ, invQt (seed + e):
+    one launch must equal E independent oracle predictions."""
+    from gp_emulator_amd import perband
+    N, D, M, E = 250, 11, 777, 7
+    rs = np.random.RandomState(42)
+    inputs = rs.random_sample((N, D))
+    testing = rs.random_sample((M, D))
+    gps = []
+    for e in range(E):
+        r = np.random.RandomState(100 + e)
+        gp = GaussianProcess(inputs, [])
+        gp.theta, gp.invQ, gp.invQt = r.random_sample(D + 2), r.random_sample((N, N)), r.random_sample(N)
+        gps.append(gp)
+    mu, var, der = perband.predict_bands(gps, testing, precision)
+    assert mu.shape == (E, M) and var.shape == (E, M) and der.shape == (E, M, D)
+    for e, gp in enumerate(gps):
+        ref = gp_oracle.cpu_predict(inputs, gp.theta, gp.invQ, gp.invQt, testing)
+        assert max(errs(ref, (mu[e], var[e], der[e]))) <= TOL[precision], e
+
+
+def test_batched_equals_single_bitwise(gpu_lib):
+    """The batched launch runs the same arithmetic per emulator as the single one."""
+    g = synthetic_case("c1_n100_d5")
+    ctx = _lib.default_context(0)
+    e = np.exp(g["theta"])
+    single = _lib.Model(ctx, e, g["inputs"], g["invQt"], g["invQ"]).predict(g["testing"][:500])
+    batch = _lib.BatchModel(ctx, np.stack([e, e, e]), g["inputs"], np.stack([g["invQt"]] * 3),
+                            np.stack([g["invQ"]] * 3)).predict(g["testing"][:500])
+    for k in range(3):
+        for a, b in zip(single, batch):
+            assert np.array_equal(a, b[k])
