@@ -46,7 +46,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--n-test", type=int, default=N_TEST)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="c2 = the metric's config (default); c3/c4/c5 = the other BASELINE configs")
+    ap.add_argument("--n-test", type=int, default=0, help="rows per GPU per step (0 = workload default)")
+    ap.add_argument("--emulators", type=int, default=2101, help="emulators in the c3 batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
     return ap.parse_args()
@@ -78,45 +81,73 @@ def cpu_baseline(sample_rows):
                       % (sample_rows, dt, blas_threads, os.cpu_count() or 0)}
 
 
+WORKLOADS = {
+    # name: (n_train, n_inputs, default rows per GPU per step, kind)
+    "c2": (250, 11, 1000000, "predict"),     # BASELINE configs[1] -- the metric's config
+    "c3": (250, 11, 100000, "batch"),        # configs[2]: 2101 emulators, shared test rows
+    "c4": (300, 11, 12500000, "predict"),    # configs[3]: 1e8 rows over 8 GPUs = 1.25e7 each
+    "c5": (300, 16, 1000000, "hessian"),     # configs[4]: full DxD Hessian
+}
+
+
+def flop_per_point(N, D, kind):
+    """SURVEY.md section 8d: 3ND [dist] + 3N + 2N [mean] + (2N^2+2N+1) [var] + (3ND+D) [grad];
+    Hessian as the reference writes it: 3ND + 3N + 7ND^2."""
+    if kind == "hessian":
+        return 3 * N * D + 3 * N + 7 * N * D * D
+    return 3 * N * D + 3 * N + 2 * N + (2 * N * N + 2 * N + 1) + (3 * N * D + D)
+
+
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from gp_emulator_amd import _lib, multi_gpu
+    from oracle import gp_oracle  # inputs recipe, parity spot check, cpu_baseline leg only
+
+    grp = multi_gpu.RankGroup()
+    rank, world = grp.rank, grp.world
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-
-    dist = None
-    if world > 1:
-        import torch  # plumbing only: rendezvous, barrier, max-reduce over ranks
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    from gp_emulator_amd import _lib
-    from oracle import gp_oracle  # inputs recipe (and the cpu_baseline leg) only
-
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
-    ctx = _lib.Context(local_rank % ndev)
+    ctx = _lib.Context(grp.local_rank % ndev)
     info = ctx.device_info()
 
+    N, D, m_default, kind = WORKLOADS[a.workload]
     dtype = np.float64 if a.precision == "f64" else np.float32
-    M = a.n_test
-    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1000 + rank, N_TRAIN,
-                                                                     N_INPUTS, M)
-    model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, dtype)
     isz = np.dtype(dtype).itemsize
+    M = a.n_test or m_default
+    E = a.emulators if kind == "batch" else 1
+    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1000 + rank, N, D, M)
     d_t = ctx.to_device(testing.astype(dtype))
-    d_mu, d_var = ctx.malloc(M * isz), ctx.malloc(M * isz)
-    d_der = ctx.malloc(M * N_INPUTS * isz)
+    if kind == "batch":
+        # shared inputs / test rows; per-emulator theta, invQ, invQt from seed + e (SURVEY 8d)
+        thetas = np.empty((E, D + 2))
+        invQs = np.empty((E, N, N), dtype=dtype)
+        invQts = np.empty((E, N))
+        for e in range(E):
+            r = np.random.RandomState(5000 + e)
+            thetas[e] = r.random_sample(D + 2)
+            invQs[e] = r.random_sample((N, N))
+            invQts[e] = r.random_sample(N)
+        model = _lib.BatchModel(ctx, np.exp(thetas), inputs, invQts, invQs, dtype)
+        if E > 64:
+            del invQs
+    else:
+        model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, dtype)
+    if kind == "hessian":
+        d_h = ctx.malloc(M * D * D * isz)
+        bufs = [d_t, d_h]
 
-    def step():
-        model.predict_device(d_t, d_mu, d_var, d_der, M, _lib.GP_DERIV_ROWMAJOR)
+        def step():
+            model.hessian_device(d_t, d_h, M)
+    else:
+        d_mu, d_var = ctx.malloc(E * M * isz), ctx.malloc(E * M * isz)
+        d_der = ctx.malloc(E * M * D * isz)
+        bufs = [d_t, d_mu, d_var, d_der]
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+        def step():
+            model.predict_device(d_t, d_mu, d_var, d_der, M, _lib.GP_DERIV_ROWMAJOR)
 
     for _ in range(a.warmup):
         step()
@@ -124,7 +155,7 @@ def main():
 
     # ---- timed region: exactly K steps, barrier + device sync on both sides ----------
     evs = [ctx.event() for _ in range(a.steps + 1)]
-    barrier()
+    grp.barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
     ctx.record(evs[0])
@@ -132,84 +163,114 @@ def main():
         step()
         ctx.record(evs[k + 1])      # HIP events on the stream the kernel is launched on
     ctx.synchronize()
-    barrier()
+    grp.barrier()
     dt = time.perf_counter() - t0
+    dt = grp.max(dt)
 
     kern_ms = [ctx.elapsed_ms(evs[k], evs[k + 1]) for k in range(a.steps)]
     kern_avg_s = float(np.mean(kern_ms)) * 1e-3
 
     # parity spot check of what was timed (after the timed region: the numpy check leaves
     # BLAS worker threads spinning, which would steal host time from the launch loop)
-    idx = np.random.RandomState(5).choice(M, 2048, replace=False)
-    mu = ctx.to_host(d_mu, (M,), dtype)[idx]
-    var = ctx.to_host(d_var, (M,), dtype)[idx]
-    der = ctx.to_host(d_der, (M, N_INPUTS), dtype)[idx]
-    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[idx])
-    errs = [gp_oracle.maxnorm_err(r, g) for r, g in zip(ref, (mu, var, der))]
+    rs = np.random.RandomState(5)
     tol = 1e-10 if a.precision == "f64" else 1e-4
+    if kind == "hessian":
+        idx = np.sort(rs.choice(M, 256, replace=False))
+        got = ctx.to_host(d_h, (M, D, D), dtype)[idx]
+        ref = gp_oracle.hessian(inputs, theta, invQt, testing[idx])
+        errs = [gp_oracle.maxnorm_err(ref, got)]
+        names = ["e_hess"]
+    else:
+        idx = rs.choice(M, 2048, replace=False)
+        e_chk = E - 1
+        mu = ctx.to_host(d_mu, (E, M), dtype)[e_chk, idx]
+        var = ctx.to_host(d_var, (E, M), dtype)[e_chk, idx]
+        if E * M * D * isz < (4 << 30):
+            der = ctx.to_host(d_der, (E, M, D), dtype)[e_chk, idx]
+        else:                             # config 3 at full size: 18 GB of gradients
+            der = None
+        if kind == "batch":
+            r = np.random.RandomState(5000 + e_chk)
+            th_c, iq_c, iqt_c = r.random_sample(D + 2), r.random_sample((N, N)), r.random_sample(N)
+        else:
+            th_c, iq_c, iqt_c = theta, invQ, invQt
+        ref = gp_oracle.cpu_predict(inputs, th_c, iq_c, iqt_c, testing[idx])
+        errs = [gp_oracle.maxnorm_err(ref[0], mu), gp_oracle.maxnorm_err(ref[1], var)]
+        names = ["e_mu", "e_var"]
+        if der is not None:
+            errs.append(gp_oracle.maxnorm_err(ref[2], der))
+            names.append("e_deriv")
     if not max(errs) <= tol:
-        raise SystemExit("bench parity check failed: %s" % errs)
-
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        raise SystemExit("bench parity check failed: %s" % dict(zip(names, errs)))
 
     out = None
     if rank == 0:
-        value = world * a.steps * M / dt
-        flop_pt = FLOP_PER_POINT
-        byte_pt = BYTES_PER_POINT if a.precision == "f64" else BYTES_PER_POINT // 2
+        units = E * M                                  # (emulator, test point) pairs per step
+        value = world * a.steps * units / dt
+        flop_pt = flop_per_point(N, D, kind)
+        if kind == "hessian":
+            byte_pt = (D + D * D) * isz
+        else:
+            byte_pt = (2 * D + 2) * isz if E == 1 else (2 + D) * isz
         peak = PEAK_FP64_TFLOPS if a.precision == "f64" else 157.3
-        achieved_tf = flop_pt * M / kern_avg_s / 1e12
+        achieved_tf = flop_pt * units / kern_avg_s / 1e12
+        hbm_gbps = byte_pt * units / kern_avg_s / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.precision)
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (a.workload, a.precision))
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        kname = {"predict": "predict_kernel", "batch": "predict_kernel", "hessian": "hessian_kernel"}[kind]
+        ctype = "double" if a.precision == "f64" else "float"
+        minfo = model.info()
+        kfull = ("%s<%s,%d,%d>" % (kname, ctype, minfo["kernel_d"], minfo["kernel_nb"])
+                 if kind != "hessian" else "%s<%s,%d>" % (kname, ctype, minfo["kernel_d"]))
+        metric = ("test-points/sec for predict(mean+var+grad), N_train=%d D=%d" % (N, D)
+                  if kind != "hessian" else
+                  "test-points/sec for hessian (full DxD), N_train=%d D=%d" % (N, D))
+        desc = {
+            "c2": "PROSAIL single-band (BASELINE configs[1]): N_train=250, D=11, N_test=%d per GPU per step, predict mean+var+grad, inputs and outputs resident in HBM" % M,
+            "c3": "MultivariateEmulator per-band (BASELINE configs[2]): %d emulators x N_train=250 x D=11, N_test=%d shared test rows in HBM, one launch per step; unit = (emulator, test point)" % (E, M),
+            "c4": "BASELINE configs[3]: N_train=300, D=11, N_test=%d per GPU per step (1e8 rows row-sharded over 8 GPUs = 1.25e7 each), predict mean+var+grad" % M,
+            "c5": "Hessian path (BASELINE configs[4]): N_train=300, D=16, N_test=%d per GPU per step, full DxD Hessian per test point" % M,
+        }[a.workload]
         out = {
-            "metric": "test-points/sec for predict(mean+var+grad), N_train=250 D=11",
+            "metric": metric,
             "value": value, "unit": "test-points/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": "PROSAIL single-band (BASELINE configs[1]): N_train=250, "
-                                   "D=11, N_test=%d per GPU per step, predict mean+var+grad, "
-                                   "inputs and outputs resident in HBM" % M,
-                       "n_train": N_TRAIN, "n_inputs": N_INPUTS, "n_test_per_gpu": M,
+            "config": {"workload": desc, "n_train": N, "n_inputs": D, "n_test_per_gpu": M,
+                       "n_emulators": E,
                        "parallelism": "row-sharded x%d, no collective" % world,
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic,
-                         "kernel": "predict_kernel<%s,11,16>" % ("double" if a.precision == "f64" else "float"),
-                         "kernel_ms": kern_avg_s * 1e3,
+                         "kernel": kfull, "kernel_ms": kern_avg_s * 1e3,
                          "flop_per_point": flop_pt,
-                         "note": "achieved = algorithmic 143262 flop/pt (un-halved variance "
-                                 "contraction, as the reference computes it) x points per "
-                                 "launch / HIP-event kernel time; the kernel executes "
-                                 "~0.53x of those MFMA flops (symmetric block-pair folding)",
-                         "hbm": {"achieved": byte_pt * M / kern_avg_s / 1e9,
-                                 "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                 "frac": byte_pt * M / kern_avg_s / 1e9 / PEAK_HBM_GBPS,
-                                 "bytes_per_point": byte_pt}},
-            "parity": {"e_mu": errs[0], "e_var": errs[1], "e_deriv": errs[2], "tol": tol,
-                       "checked_rows": 2048},
+                         "note": ("achieved = algorithmic flop/pt of SURVEY.md 8d (un-halved variance "
+                                  "contraction / Hessian as the reference writes it) x units per launch "
+                                  "/ HIP-event kernel time.  The kernel EXECUTES fewer flops than that "
+                                  "(symmetric block-pair folding of the variance: 0.53x of its MFMAs; "
+                                  "Hessian: D(D+1)/2 products), which is how frac can exceed 1; peak is "
+                                  "the fp64 matrix (= vector) datasheet rate, measured MFMA-only ceiling "
+                                  "on this chip 71.4 TFLOP/s (profiles/r01_mfma_f64_probe.txt)"),
+                         "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                 "frac": hbm_gbps / PEAK_HBM_GBPS, "bytes_per_point": byte_pt}},
+            "parity": dict(zip(names, errs), tol=tol, checked_rows=int(len(idx))),
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
 
-    for p in (d_t, d_mu, d_var, d_der):
+    for p in bufs:
         ctx.free(p)
     for e in evs:
         ctx.event_destroy(e)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
     return out
 
 

@@ -1,0 +1,141 @@
+"""Row-sharded predict over the GPUs of one node, and the rank plumbing bench.py uses.
+
+Every output row depends only on its own test row plus read-only per-emulator constants
+(gp_emulator/GaussianProcess.py:232-247; "all inputs can be divided and distributed
+arbitrarily", doc/report.md:95), so the path shards into independent contiguous row blocks:
+GPU g gets rows [g*ceil(M/G), min(M, (g+1)*ceil(M/G))), constants (< 1 MB) are replicated,
+and each device writes its own disjoint slice of the caller's arrays.  There is NO
+collective on the data path -- nothing here touches RCCL.
+
+Two ways to drive several GPUs:
+  * ``predict_sharded``: one process, one Python thread per device (ctypes releases the GIL
+    during C-ABI calls; a gp_ctx is per thread/device), host gather into disjoint slices;
+  * one process per GPU under ``torch.distributed.run`` (how bench.py is launched): the only
+    communication is the timing barrier / max-reduce in ``RankGroup``, over gloo.
+"""
+import os
+import threading
+import time
+
+import numpy as np
+
+
+def row_shards(n_rows, n_shards):
+    """Contiguous row blocks [(start, end)] of equal ceil size; trailing shards may be
+    empty when n_rows < n_shards."""
+    n_rows, n_shards = int(n_rows), int(n_shards)
+    if n_shards <= 0:
+        raise ValueError("n_shards must be positive")
+    per = -(-n_rows // n_shards) if n_rows > 0 else 0
+    out = []
+    for g in range(n_shards):
+        s = min(n_rows, g * per)
+        e = min(n_rows, (g + 1) * per)
+        out.append((s, e))
+    return out
+
+
+def predict_sharded(gp, testing, devices, precision=np.float64, predict_fn=None):
+    """mean, variance, gradient of ``gp`` at ``testing`` with rows sharded over ``devices``.
+
+    ``predict_fn(device, rows) -> (mu, var, deriv)`` defaults to the HIP path (a Model per
+    device); the CPU tests pass a stand-in to exercise the sharding/gather logic alone.
+    """
+    testing = np.ascontiguousarray(testing)
+    M, D = testing.shape
+    mu = np.empty(M)
+    var = np.empty(M)
+    deriv = np.empty((M, D))
+    shards = row_shards(M, len(devices))
+    errors = []
+
+    if predict_fn is None:
+        from . import _lib
+
+        def predict_fn(device, rows):
+            ctx = _lib.default_context(device)      # per-thread context on that device
+            model = _lib.Model(ctx, np.exp(gp.theta), gp.inputs, gp.invQt, gp.invQ, precision)
+            try:
+                return model.predict(rows)
+            finally:
+                model.close()
+
+    def work(device, s, e):
+        try:
+            if e > s:
+                m_, v_, d_ = predict_fn(device, testing[s:e])
+                mu[s:e], var[s:e], deriv[s:e] = m_, v_, d_
+        except BaseException as exc:   # surfaced to the caller below
+            errors.append((device, exc))
+
+    threads = [threading.Thread(target=work, args=(dev, s, e))
+               for dev, (s, e) in zip(devices, shards)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0][1]
+    return mu, var, deriv
+
+
+class RankGroup:
+    """Barrier + max-reduce over the ranks of a torch.distributed.run launch (gloo).
+
+    world == 1 needs no torch at all.  Only scalars cross ranks: the data path has no
+    exchange step, so no RCCL collective exists to call.
+    """
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, value):
+        if self.dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, value):
+        if self.dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def timed_steps(group, step, sync, steps, warmup):
+    """bench.py's timing contract: W untimed steps, then EXACTLY K steps bracketed by a
+    barrier + device sync on both sides; returns the MAX over ranks of the wall time."""
+    for _ in range(warmup):
+        step()
+    sync()
+    group.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    group.barrier()
+    dt = time.perf_counter() - t0
+    return group.max(dt)
