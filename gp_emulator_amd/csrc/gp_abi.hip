@@ -365,8 +365,8 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   const int64_t groups = (M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG * m->n_emulators;
   if ((M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG > 0x7fffffffLL)
     return fail(GP_ERR_INVALID, "n_predict too large for one launch");
-  // persistent grid: 2 workgroups per CU (the kernel's occupancy), grid-stride over groups
-  int64_t grid = (int64_t)ctx->compute_units * 2;
+  // persistent grid: the kernel's occupancy (2 waves per SIMD), grid-stride over work items
+  int64_t grid = (int64_t)ctx->compute_units * gpk::kWGPerCU;
   if (grid > groups) grid = groups;
   hipError_t e = launch<T>(m->kernel_nb, m->kernel_d, a, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(GP_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -394,7 +394,7 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.M = M;
   a.d_actual = m->n_inputs;
   a.nb = (m->n_train + 15) / 16;     // the loop over training points is a run-time loop
-  const int64_t groups = (M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG;
+  const int64_t groups = (M + gpk::hkRowsPerWG - 1) / gpk::hkRowsPerWG;
   int64_t grid = (int64_t)ctx->compute_units * 2;
   if (grid > groups) grid = groups;
   hipError_t e = launch_hessian<T>(m->kernel_d, a, (int)grid, ctx->stream);

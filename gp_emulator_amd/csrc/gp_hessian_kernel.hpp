@@ -32,8 +32,14 @@ struct HessianArgs {
   int nb;             // 16-row blocks of training points
 };
 
+// Hessian kernel geometry: 4 waves (one per SIMD) so that the D = 16 instance, which needs
+// ~380 registers, still fits (one wave per SIMD).
+constexpr int hkWaves = 4;
+constexpr int hkThreads = hkWaves * 64;
+constexpr int hkRowsPerWG = hkWaves * kTile;
+
 template <typename T, int D>
-__global__ __launch_bounds__(kThreads, 1) void hessian_kernel(HessianArgs<T> p) {
+__global__ __launch_bounds__(hkThreads, 1) void hessian_kernel(HessianArgs<T> p) {
   typedef Real<T> R;
   constexpr int DS = row_stride(D);
   constexpr int NPAIR = D * (D + 1) / 2;
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(kThreads, 1) void hessian_kernel(HessianArgs<T> p) 
   const int g = lane >> 4;
   const int np = 16 * p.nb;
 
-  for (int i = tid; i < np * DS; i += kThreads) s_xa[i] = p.xa[i];
+  for (int i = tid; i < np * DS; i += hkThreads) s_xa[i] = p.xa[i];
   // sqrt(e_d) and the centre stay in LDS (broadcast reads), not in registers: the
   // D(D+1)/2 accumulators need the register file
   T* s_sd = s_xa + np * DS;
@@ -55,9 +61,9 @@ __global__ __launch_bounds__(kThreads, 1) void hessian_kernel(HessianArgs<T> p) 
   const T b = p.sd[2 * D];
   __syncthreads();
 
-  const long long n_groups = (p.M + kRowsPerWG - 1) / kRowsPerWG;
+  const long long n_groups = (p.M + hkRowsPerWG - 1) / hkRowsPerWG;
   for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const long long m = grp * kRowsPerWG + wave * kTile + ml;
+    const long long m = grp * hkRowsPerWG + wave * kTile + ml;
     const long long mc = m < p.M ? m : p.M - 1;
     T t[D];
 #pragma unroll

@@ -13,7 +13,7 @@ static hipError_t launch_one(const HessianArgs<GP_T>& a, int grid, size_t lds, h
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian_kernel<GP_T, D>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((hessian_kernel<GP_T, D>), dim3(grid), dim3(kThreads), lds, stream, a);
+  hipLaunchKernelGGL((hessian_kernel<GP_T, D>), dim3(grid), dim3(hkThreads), lds, stream, a);
   return hipGetLastError();
 }
 

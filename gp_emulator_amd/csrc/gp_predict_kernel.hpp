@@ -29,11 +29,23 @@
 
 namespace gpk {
 
-constexpr int kWaves = 4;            // waves per workgroup (one per SIMD)
+#ifndef GP_WAVES
+#define GP_WAVES 8
+#endif
+#ifndef GP_CHUNK
+#define GP_CHUNK 64
+#endif
+// Predict kernel geometry.  8 waves = two per SIMD, all in the same phase: fp64 MFMA and fp64
+// VALU share one pipe on MI355X (tools/mfma_f64_probe.hip), so there is nothing to gain from
+// running a VALU-phase workgroup beside an MFMA-phase one, and partners in the same phase keep
+// the workgroup's waves in step (short barrier waits) while each fragment staged in LDS now
+// feeds 8 waves instead of 4.
+constexpr int kWaves = GP_WAVES;     // waves per workgroup
 constexpr int kThreads = kWaves * 64;
+constexpr int kWGPerCU = 8 / kWaves; // 2 waves per SIMD either way
 constexpr int kTile = 16;            // test rows per wave tile (MFMA N dimension)
 constexpr int kRowsPerWG = kWaves * kTile;
-constexpr int kChunk = 32;           // A-operand fragments per LDS chunk
+constexpr int kChunk = GP_CHUNK;     // A-operand fragments per LDS chunk
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -176,7 +188,7 @@ __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int 
   constexpr int kPerWave = kBytes / kWaves;       // bytes each wave moves
   constexpr int kIters = kPerWave / 1024;
   static_assert(kIters * 1024 * kWaves == kBytes, "chunk must be whole 1 KiB pieces per wave");
-  static_assert(kIters == 4 || kIters == 2, "unexpected chunk size");
+  static_assert(kIters == 4 || kIters == 2 || kIters == 1, "unexpected chunk size");
   // wave-uniform SGPR source base, 32-bit per-lane VGPR offset (saddr form); the
   // instruction's immediate offset applies to BOTH the global and the LDS address
   const char* s = reinterpret_cast<const char*>(src) + wave * kPerWave;
@@ -195,12 +207,20 @@ __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int 
         :
         : "s"(m0v), "v"(voff), "s"(s)
         : "memory");
-  } else {
+  } else if constexpr (kIters == 2) {
     asm volatile(
         "s_mov_b32 m0, %0\n\t"
         "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
         "global_load_lds_dwordx4 %1, %2\n\t"
         "global_load_lds_dwordx4 %1, %2 offset:1024"
+        :
+        : "s"(m0v), "v"(voff), "s"(s)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
+        "global_load_lds_dwordx4 %1, %2"
         :
         : "s"(m0v), "v"(voff), "s"(s)
         : "memory");
