@@ -30,6 +30,11 @@ __all__ = ["GaussianProcess"]
 class GaussianProcess:
     """Squared-exponential ARD Gaussian-process emulator (predict side)."""
 
+    # gpu_predict crosses the boundary with predict_rows (row-major gradient written
+    # straight into the arrays it returns) unless this is False, in which case it calls
+    # the reference's predict_wrap and un-transposes, exactly as reference :313-321.
+    row_major_boundary = True
+
     def __init__(self, inputs, targets):
         # gp_emulator/GaussianProcess.py:35-51
         self.inputs = inputs
@@ -120,22 +125,37 @@ class GaussianProcess:
         invQ = cast(self.invQ, n_train * n_train)
         expX = cast(np.exp(self.theta), theta_size)
 
-        result = np.zeros(n_predict)
-        error = np.zeros(n_predict)
-        deriv = np.zeros((n_predict, n_inputs))
+        result = np.empty(n_predict)
+        error = np.empty(n_predict)
+        deriv = np.empty((n_predict, n_inputs))
         ind_start, ind_end = self.get_gpu_block(n_predict, threshold)
+        direct = self.row_major_boundary and precision == np.float64
         for block_start, block_end in zip(ind_start, ind_end):
             n_blk = int(block_end - block_start)
             testing_block = cast(testing[block_start:block_end, :], n_blk * n_inputs)
+            if direct:
+                # float64: the library writes into the final arrays' own slices
+                _gpu_predict.predict_rows(expX, inputs, invQt, invQ, testing_block,
+                                          result[block_start:block_end],
+                                          error[block_start:block_end],
+                                          deriv[block_start:block_end, :].reshape(-1),
+                                          n_blk, n_train, n_inputs, theta_size)
+                continue
             result_block = np.zeros(n_blk, dtype=precision)
             error_block = np.zeros(n_blk, dtype=precision)
             deriv_block = np.zeros(n_blk * n_inputs, dtype=precision)
-            _gpu_predict.predict_wrap(expX, inputs, invQt, invQ, testing_block,
-                                      result_block, error_block, deriv_block,
-                                      n_blk, n_train, n_inputs, theta_size)
+            if self.row_major_boundary:
+                _gpu_predict.predict_rows(expX, inputs, invQt, invQ, testing_block,
+                                          result_block, error_block, deriv_block,
+                                          n_blk, n_train, n_inputs, theta_size)
+                deriv[block_start:block_end, :] = deriv_block.reshape(n_blk, n_inputs)
+            else:
+                _gpu_predict.predict_wrap(expX, inputs, invQt, invQ, testing_block,
+                                          result_block, error_block, deriv_block,
+                                          n_blk, n_train, n_inputs, theta_size)
+                deriv[block_start:block_end, :] = deriv_block.reshape(n_inputs, n_blk).T
             result[block_start:block_end] = result_block
             error[block_start:block_end] = error_block
-            deriv[block_start:block_end, :] = deriv_block.reshape(n_inputs, n_blk).T
         return result, error, deriv
 
     def predict(self, testing, do_unc=True, is_gpu=False, precision=np.float64, threshold=2e5):

@@ -26,6 +26,22 @@ _NAMES = ("expX", "inputs", "invQt", "invQ", "testing", "result", "error", "deri
 
 def predict_wrap(expX, inputs, invQt, invQ, testing, result, error, deriv,
                  n_predict, n_train, n_inputs, theta_size):
+    """The reference entry point: ``deriv`` comes back dimension-major."""
+    return _call("wrap", expX, inputs, invQt, invQ, testing, result, error, deriv,
+                 n_predict, n_train, n_inputs, theta_size)
+
+
+def predict_rows(expX, inputs, invQt, invQ, testing, result, error, deriv,
+                 n_predict, n_train, n_inputs, theta_size):
+    """Same twelve arguments, but ``deriv`` is written row-major ``(n_predict, n_inputs)``
+    (flattened) -- what ``gpu_predict`` returns after its transpose (reference :321) -- so
+    the host needs no strided copy.  Not part of the reference module."""
+    return _call("rows", expX, inputs, invQt, invQ, testing, result, error, deriv,
+                 n_predict, n_train, n_inputs, theta_size)
+
+
+def _call(kind, expX, inputs, invQt, invQ, testing, result, error, deriv,
+          n_predict, n_train, n_inputs, theta_size):
     arrays = (expX, inputs, invQt, invQ, testing, result, error, deriv)
     for name, a in zip(_NAMES, arrays):
         if not isinstance(a, np.ndarray):
@@ -53,7 +69,8 @@ def predict_wrap(expX, inputs, invQt, invQ, testing, result, error, deriv,
         if not dict(zip(_NAMES, arrays))[name].flags["WRITEABLE"]:
             raise ValueError("%s must be writeable" % name)
     ctx = _lib.default_context(0)
-    fn = ctx.lib.gp_predict_wrap_f64 if dt == np.float64 else ctx.lib.gp_predict_wrap_f32
+    name = "gp_predict_%s_%s" % (kind, "f64" if dt == np.float64 else "f32")
+    fn = getattr(ctx.lib, name)
     p = [a.ctypes.data_as(_lib.c_void_p) for a in arrays]
     _lib.check(fn(ctx.h, *p, n_predict, n_train, n_inputs, theta_size), "gp_predict_wrap")
     return None

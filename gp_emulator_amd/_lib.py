@@ -11,7 +11,9 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgp_predict_hip.so")
+# GP_PREDICT_LIB lets tools/ab_bench.py time differently-built variants of the library on
+# one device; it never points at anything but a build of this repo's csrc/.
+LIB_PATH = os.environ.get("GP_PREDICT_LIB") or os.path.join(HERE, "libgp_predict_hip.so")
 
 GP_F32, GP_F64 = 0, 1
 GP_DERIV_DMAJOR, GP_DERIV_ROWMAJOR = 0, 1
@@ -33,6 +35,8 @@ SIGNATURES = {
                                    ctypes.c_char_p, c_int]),
     "gp_predict_wrap_f64": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
     "gp_predict_wrap_f32": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
+    "gp_predict_rows_f64": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
+    "gp_predict_rows_f32": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
     "gp_model_create_f64": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_model_create_f32": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_batch_create_f64": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),

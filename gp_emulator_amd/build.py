@@ -52,10 +52,23 @@ def run(cmd):
     return r.stdout
 
 
-def build(force=False, jobs=None, verbose=True):
+def build(force=False, jobs=None, verbose=True, defines=(), lib=None, only_nb=None):
+    """Compile and link.  ``defines`` (e.g. ["-DGP_WAVES=4"]), ``lib`` (output path) and
+    ``only_nb`` (restrict the kernel set) exist for tools/ab_bench.py variants only."""
+    global OBJ, LIB
+    variant = bool(defines or lib or only_nb)
+    obj_dir, lib_path = OBJ, LIB
+    if variant:
+        tag = hashlib.sha256((" ".join(defines) + str(only_nb)).encode()).hexdigest()[:10]
+        obj_dir = os.path.join(CSRC, "_obj", "variant_" + tag)
+        lib_path = lib or os.path.join(HERE, "libgp_predict_hip_%s.so" % tag)
+    return _build(force, jobs, verbose, list(defines), obj_dir, lib_path, only_nb)
+
+
+def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
     os.makedirs(OBJ, exist_ok=True)
     stamp = os.path.join(OBJ, "digest.txt")
-    digest = source_digest()
+    digest = source_digest() + " ".join(defines) + str(only_nb)
     if (not force and os.path.exists(LIB) and os.path.exists(stamp)
             and open(stamp).read().strip() == digest):
         if verbose:
@@ -66,14 +79,14 @@ def build(force=False, jobs=None, verbose=True):
     for tname, ctype in (("f64", "double"), ("f32", "float")):
         for nb in kernel_nbs():
             obj = os.path.join(OBJ, "kern_%s_%d.o" % (tname, nb))
-            tasks.append([HIPCC] + FLAGS + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
+            tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
                                             "-DGP_NB=%d" % nb, "-c",
                                             os.path.join(CSRC, "gp_kernels_tu.hip"), "-o", obj])
         obj = os.path.join(OBJ, "hess_%s.o" % tname)
-        tasks.append([HIPCC] + FLAGS + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
+        tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
                                         os.path.join(CSRC, "gp_hessian_tu.hip"), "-o", obj])
     abi_obj = os.path.join(OBJ, "gp_abi.o")
-    tasks.append([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, "gp_abi.hip"), "-o", abi_obj])
+    tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_abi.hip"), "-o", abi_obj])
     # biggest kernels first so the pool drains evenly
     tasks.sort(key=lambda c: -int(next((a[8:] for a in c if a.startswith("-DGP_NB=")), "0")))
     if verbose:
@@ -95,9 +108,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--define", action="append", default=[], help="extra -D flag (variant build)")
+    ap.add_argument("--lib", default=None, help="output path (variant build)")
     a = ap.parse_args()
     try:
-        build(force=a.force, jobs=a.jobs)
+        build(force=a.force, jobs=a.jobs, defines=["-D" + d for d in a.define], lib=a.lib)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

@@ -420,7 +420,7 @@ static int ensure_scratch(gp_ctx* ctx, size_t bytes) {
 template <typename T>
 static int predict_wrap(gp_ctx* ctx, const T* expX, const T* inputs, const T* invQt,
                         const T* invQ, const T* testing, T* result, T* error, T* deriv,
-                        int64_t M, int N, int D, int theta_size) {
+                        int64_t M, int N, int D, int theta_size, int layout = GP_DERIV_DMAJOR) {
   if (!ctx) return fail(GP_ERR_INVALID, "null context");
   if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
   if (M > 0 && (!testing || !result || !error || !deriv)) return fail(GP_ERR_INVALID, "null pointer");
@@ -441,14 +441,20 @@ static int predict_wrap(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
     T* d_der = d_var + n;
     e = hipMemcpyAsync(d_t, testing + (size_t)s0 * D, sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) break;
-    rc = predict_device<T>(ctx, m, d_t, d_mu, d_var, d_der, n, GP_DERIV_DMAJOR);
+    rc = predict_device<T>(ctx, m, d_t, d_mu, d_var, d_der, n, layout);
     if (rc) break;
     e = hipMemcpyAsync(result + s0, d_mu, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(error + s0, d_var, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
-    // deriv is dimension-major over the WHOLE call: row d of the slab goes to d*M + s0
-    for (int d = 0; d < D && e == hipSuccess; ++d)
-      e = hipMemcpyAsync(deriv + (size_t)d * M + s0, d_der + (size_t)d * n, sizeof(T) * (size_t)n,
-                         hipMemcpyDeviceToHost, ctx->stream);
+    if (layout == GP_DERIV_ROWMAJOR) {
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(deriv + (size_t)s0 * D, d_der, sizeof(T) * (size_t)n * D,
+                           hipMemcpyDeviceToHost, ctx->stream);
+    } else {
+      // deriv is dimension-major over the WHOLE call: row d of the slab goes to d*M + s0
+      for (int d = 0; d < D && e == hipSuccess; ++d)
+        e = hipMemcpyAsync(deriv + (size_t)d * M + s0, d_der + (size_t)d * n, sizeof(T) * (size_t)n,
+                           hipMemcpyDeviceToHost, ctx->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
   gp_model_destroy(m);
@@ -585,6 +591,19 @@ int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const fl
                    const float* testing, float* hess, int64_t n_predict, int n_train,
                    int n_inputs, int theta_size) {
   return hessian_host<float>(ctx, expX, inputs, invQt, testing, hess, n_predict, n_train, n_inputs, theta_size);
+}
+
+int gp_predict_rows_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
+                        const double* invQ, const double* testing, double* result, double* error,
+                        double* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
+  return predict_wrap<double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                              n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
+}
+int gp_predict_rows_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
+                        const float* invQ, const float* testing, float* result, float* error,
+                        float* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
+  return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                             n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
 }
 
 int gp_malloc(gp_ctx* ctx, int64_t bytes, void** dptr) {

@@ -35,6 +35,9 @@ namespace gpk {
 #ifndef GP_CHUNK
 #define GP_CHUNK 64
 #endif
+#ifndef GP_PREFETCH
+#define GP_PREFETCH 1   // fetch the next item's test rows during the matrix-core phase
+#endif
 // Predict kernel geometry.  8 waves = two per SIMD, all in the same phase: fp64 MFMA and fp64
 // VALU share one pipe on MI355X (tools/mfma_f64_probe.hip), so there is nothing to gain from
 // running a VALU-phase workgroup beside an MFMA-phase one, and partners in the same phase keep
@@ -257,6 +260,19 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
   int e = 0, cur_e = -1;
   int grp = blockIdx.x;
   while (grp >= n_groups && e < p.n_emulators) { grp -= n_groups; ++e; }
+
+  // Raw test rows of the CURRENT item; the next item's are fetched while the matrix-core
+  // phase runs (all waves of a workgroup are in step, so nothing else would hide the
+  // HBM/L2 latency of these loads at the top of an item).
+  auto load_rows = [&](int grp_, T* dst) {
+    const long long m_ = (long long)grp_ * kRowsPerWG + wave * kTile + ml;
+    const long long mc_ = m_ < p.M ? m_ : p.M - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dst[d] = (d < p.d_actual) ? p.testing[mc_ * p.d_actual + d] : T(0);
+  };
+  T traw[D];
+  if (e < p.n_emulators) load_rows(grp, traw);
+
   for (; e < p.n_emulators;) {
     if (e != cur_e) {   // (re)load this emulator's training rows and scalars
       cur_e = e;
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
     T gm = T(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      t[d] = (d < p.d_actual) ? s_sd[d] * (p.testing[mc * p.d_actual + d] - s_sd[D + d]) : T(0);
+      t[d] = (d < p.d_actual) ? s_sd[d] * (traw[d] - s_sd[D + d]) : T(0);
       gm = fma(t[d], t[d], gm);
     }
     gm *= T(-0.5);
@@ -344,6 +360,13 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
       }
     }
 
+    // next item (scalar bookkeeping) and its test rows, in flight during phase B
+    int e_next = e, grp_next = grp + gridDim.x;
+    while (grp_next >= n_groups && e_next < p.n_emulators) { grp_next -= n_groups; ++e_next; }
+#if GP_PREFETCH
+    if (e_next < p.n_emulators) load_rows(grp_next, traw);
+#endif
+
     // ---------------- phase B: variance on the matrix core -----------------
     T vacc = T(0);
     acc_t acc;
@@ -369,8 +392,11 @@ __global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) 
     vacc = xor_reduce_groups(vacc);
     if (m < p.M && g == 1) o_var[m] = b - vacc;
 
-    grp += gridDim.x;
-    while (grp >= n_groups && e < p.n_emulators) { grp -= n_groups; ++e; }
+    e = e_next;
+    grp = grp_next;
+#if !GP_PREFETCH
+    if (e < p.n_emulators) load_rows(grp, traw);
+#endif
   }
 }
 

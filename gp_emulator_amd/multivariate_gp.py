@@ -1,0 +1,121 @@
+"""Host-side mirror of the reference's ``MultivariateEmulator`` (predict side).
+
+gp_emulator/multivariate_gp.py:38-222: a multivariate model output (e.g. a 2101-band
+spectrum) is compressed onto ``n_pcs`` principal components and each PC weight is emulated
+by its own ``GaussianProcess`` on the shared training parameters ``y``.  This mirror keeps
+the constructor, ``compress``, ``predict`` and ``dump_emulator`` with the reference's
+argument names and return shapes, and loads the reference's ``.npz`` dumps (:68-79,
+e.g. data/prosail_30_0_30_0.npz) with ``allow_pickle=False``.
+
+Out of scope here, as in GaussianProcess.py: training.  ``hyperparams`` must be supplied
+(directly or through ``dump``); the reference's ``learn_hyperparameters`` path (:175-184)
+raises ``NotImplementedError``.
+"""
+import numpy as np
+
+from .GaussianProcess import GaussianProcess
+
+__all__ = ["MultivariateEmulator"]
+
+
+class MultivariateEmulator(object):
+
+    def __init__(self, dump=None, X=None, y=None, hyperparams=None, thresh=0.98, n_tries=5):
+        # reference :40-122
+        basis_functions = None
+        n_pcs = None
+        if dump is not None:
+            if X is None and y is None:
+                with np.load(dump, allow_pickle=False) as f:
+                    X = f["X"]
+                    y = f["y"]
+                    hyperparams = f["hyperparams"]
+                    thresh = float(f["thresh"])
+                    if "basis_functions" in f.files:
+                        basis_functions = f["basis_functions"]
+                        n_pcs = int(f["n_pcs"])
+            else:
+                raise ValueError("You specified both a dump file and X and y")
+        else:
+            if X is None or y is None:
+                raise ValueError("Need to specify both X and y")
+            assert X.shape[0] == y.shape[0]
+            assert X.ndim == 2
+            assert y.ndim == 2
+
+        self.X_train = X
+        self.y_train = y
+        self.thresh = thresh
+        if basis_functions is None:
+            self.calculate_decomposition(X, thresh)
+            basis_functions = self.basis_functions
+            n_pcs = self.n_pcs
+        self.n_pcs = int(n_pcs)
+        self.basis_functions = basis_functions
+        if hyperparams is not None:
+            assert (y.shape[1] + 2 == hyperparams.shape[0]) and (self.n_pcs == hyperparams.shape[1])
+        self.train_emulators(X, y, hyperparams=hyperparams, n_tries=n_tries)
+
+    def dump_emulator(self, fname):
+        """Save in the reference's .npz layout (reference :124-137)."""
+        np.savez_compressed(fname, X=self.X_train, y=self.y_train, hyperparams=self.hyperparams,
+                            thresh=self.thresh, basis_functions=self.basis_functions,
+                            n_pcs=self.n_pcs)
+
+    def calculate_decomposition(self, X, thresh):
+        """PCA by SVD; keep the PCs whose cumulative singular-value share is <= thresh
+        (reference :139-160)."""
+        U, s, V = np.linalg.svd(X, full_matrices=True)
+        pcnt_var_explained = s.cumsum() / s.sum()
+        # the reference indexes V (N_full rows) with a mask of len(s) = min(N_train, N_full)
+        # entries (:158), which old numpy tolerated; select among the first len(s) rows
+        self.basis_functions = V[:s.size][pcnt_var_explained <= thresh]
+        self.n_pcs = int(np.sum(pcnt_var_explained <= thresh))
+
+    def train_emulators(self, X, y, hyperparams, n_tries=2):
+        """One GaussianProcess per PC on the shared inputs (reference :162-188)."""
+        if hyperparams is None:
+            raise NotImplementedError(
+                "hyper-parameter learning (GaussianProcess.learn_hyperparameters) is outside "
+                "this package's scope; pass hyperparams or a dump file")
+        self.emulators = []
+        train_data = self.compress(X)
+        self.hyperparams = np.zeros((2 + y.shape[1], self.n_pcs))
+        for i in range(self.n_pcs):
+            gp = GaussianProcess(np.atleast_2d(y), train_data[i])
+            self.hyperparams[:, i] = hyperparams[:, i]
+            gp._set_params(hyperparams[:, i])
+            self.emulators.append(gp)
+
+    def compress(self, X):
+        """Project full-rank vectors onto the PC basis (reference :190-193)."""
+        return X.dot(self.basis_functions.T).T
+
+    def predict(self, y, do_deriv=True, is_gpu=False):
+        """Reconstructed output and its Jacobian at ONE input vector ``y`` (reference
+        :195-222): ``fwd (N_full,)`` and ``deriv (N_params, N_full)``.  ``is_gpu`` is handed
+        to every per-PC ``GaussianProcess.predict`` exactly as the reference does (:215)."""
+        fwd = np.zeros(self.basis_functions[0].shape[0])
+        y = np.atleast_2d(y)
+        if do_deriv:
+            deriv = np.zeros((y.shape[1], self.basis_functions.shape[1]))
+        for i in range(self.n_pcs):
+            pred_mu, pred_var, grad = self.emulators[i].predict(y, is_gpu=is_gpu)
+            fwd += pred_mu * self.basis_functions[i]
+            if do_deriv:
+                deriv += np.asarray(grad).T @ np.atleast_2d(self.basis_functions[i])
+        if do_deriv:
+            return fwd.squeeze(), deriv
+        return fwd.squeeze()
+
+    def predict_many(self, Y, is_gpu=True, precision=np.float64):
+        """Beyond the reference (whose predict breaks for more than one row, SURVEY.md
+        section 3.3): reconstructed outputs ``(M, N_full)`` for M input rows.  On the GPU the
+        n_pcs emulators run as ONE batched launch over the shared rows."""
+        Y = np.atleast_2d(Y)
+        if is_gpu:
+            from . import perband
+            mu, _, _ = perband.predict_bands(self.emulators, Y, precision)
+        else:
+            mu = np.stack([gp.predict(Y)[0] for gp in self.emulators])
+        return mu.T @ self.basis_functions

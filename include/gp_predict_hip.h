@@ -86,6 +86,18 @@ int gp_predict_wrap_f32(gp_ctx* ctx, const float* expX, const float* inputs,
                         float* result, float* error, float* deriv,
                         int64_t n_predict, int n_train, int n_inputs, int theta_size);
 
+/* predict_wrap with the gradient written ROW-MAJOR, (n_predict, n_inputs): the layout
+ * GaussianProcess.gpu_predict finally returns (it transposes predict_wrap's output at
+ * GaussianProcess.py:321).  Same twelve arguments; saves the caller a strided host copy. */
+int gp_predict_rows_f64(gp_ctx* ctx, const double* expX, const double* inputs,
+                        const double* invQt, const double* invQ, const double* testing,
+                        double* result, double* error, double* deriv,
+                        int64_t n_predict, int n_train, int n_inputs, int theta_size);
+int gp_predict_rows_f32(gp_ctx* ctx, const float* expX, const float* inputs,
+                        const float* invQt, const float* invQ, const float* testing,
+                        float* result, float* error, float* deriv,
+                        int64_t n_predict, int n_train, int n_inputs, int theta_size);
+
 /* ---- device-resident form --------------------------------------------------------------
  * gp_model_create_*: pack (host side, in double) and upload the per-emulator constants the
  * reference re-uploads for every block (predict.cu:17-33): sqrt(e)-scaled training inputs

@@ -172,3 +172,40 @@ def test_predict_wrap_argument_checks():
     with pytest.raises(TypeError):
         _gpu_predict.predict_wrap([1.0, 2, 3], *good[1:], 2, 2, 1, 3)
     del f
+
+
+def make_mv_dump(tmp_path):
+    """Write the golden emulator back out in the reference's .npz layout."""
+    from conftest import load_golden
+    g = load_golden("prosail_mv")
+    # X is only used through compress(X) = train_data; rebuild an X with that projection
+    X = g["train_data"].T @ g["basis_functions"]
+    path = tmp_path / "emu.npz"
+    np.savez_compressed(path, X=X, y=g["y_train"], hyperparams=g["hyperparams"], thresh=0.99,
+                        basis_functions=g["basis_functions"], n_pcs=int(g["n_pcs"]))
+    return g, str(path)
+
+
+def test_multivariate_emulator_cpu_matches_reference_outputs(tmp_path):
+    """MultivariateEmulator(dump=...).predict(y) against the reference's own outputs
+    (tests/golden/prosail_mv.npz), numpy branch."""
+    from gp_emulator_amd import MultivariateEmulator
+    g, path = make_mv_dump(tmp_path)
+    mv = MultivariateEmulator(dump=path)
+    assert mv.n_pcs == 12 and len(mv.emulators) == 12
+    # the basis rows are orthonormal, so compress(X) reproduces train_data
+    assert np.max(np.abs(mv.compress(mv.X_train) - g["train_data"])) < 1e-9
+    for j, p in enumerate(g["points"][:2]):
+        fwd, jac = mv.predict(p)
+        assert fwd.shape == (2101,) and jac.shape == (10, 2101)
+        assert np.max(np.abs(fwd - g["fwd"][j])) <= 1e-6
+        assert np.max(np.abs(jac - g["jac"][j])) / np.max(np.abs(g["jac"][j])) <= 1e-5
+    assert np.max(np.abs(mv.predict(g["points"][0], do_deriv=False) - g["fwd"][0])) <= 1e-6
+    many = mv.predict_many(g["points"], is_gpu=False)
+    assert np.max(np.abs(many - g["fwd"])) <= 1e-6
+    out = tmp_path / "again.npz"
+    mv.dump_emulator(str(out))
+    with np.load(str(out), allow_pickle=False) as f:
+        assert sorted(f.files) == ["X", "basis_functions", "hyperparams", "n_pcs", "thresh", "y"]
+    with pytest.raises(NotImplementedError):
+        MultivariateEmulator(X=mv.X_train, y=mv.y_train)

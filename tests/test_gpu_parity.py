@@ -87,6 +87,11 @@ def test_gaussianprocess_predict_flow(gpu_lib, precision):
     assert got[0].dtype == np.float64 and got[2].shape == (25000, 10)
     assert max(errs(ref, got)) <= TOL[precision]
     assert max(errs(ref, got)) <= 1e-5          # the reference's own pass mark
+    # the same flow through the reference's dimension-major predict_wrap + un-transpose
+    gp.row_major_boundary = False
+    got2 = gp.predict(testing, is_gpu=True, precision=precision, threshold=1e4)
+    for x, y in zip(got, got2):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("M", [1, 15, 16, 17, 63, 64, 65, 127, 129, 1000])
@@ -261,3 +266,18 @@ def test_batched_equals_single_bitwise(gpu_lib):
     for k in range(3):
         for a, b in zip(single, batch):
             assert np.array_equal(a, b[k])
+
+
+def test_multivariate_emulator_gpu(gpu_lib, tmp_path):
+    """MultivariateEmulator.predict(y, is_gpu=True) (12 per-PC GPs through predict_wrap) and
+    the batched predict_many against the reference's outputs."""
+    from test_abi_cpu import make_mv_dump
+    from gp_emulator_amd import MultivariateEmulator
+    g, path = make_mv_dump(tmp_path)
+    mv = MultivariateEmulator(dump=path)
+    fwd, jac = mv.predict(g["points"][2], is_gpu=True)
+    assert np.max(np.abs(fwd - g["fwd"][2])) <= 1e-6
+    assert np.max(np.abs(jac - g["jac"][2])) / np.max(np.abs(g["jac"][2])) <= 1e-5
+    many = mv.predict_many(g["points"], is_gpu=True)
+    assert many.shape == (4, 2101)
+    assert np.max(np.abs(many - g["fwd"])) <= 1e-6

@@ -8,8 +8,19 @@
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
+// shader clock during the kernel = delta s_memtime / delta s_memrealtime x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6); written by lane 0 of block 0
+__device__ unsigned long long g_clk[4];
+__device__ inline void stamp(int which) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk[which] = __builtin_amdgcn_s_memtime();
+    g_clk[which + 2] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
 template <int NACC, int VALU_PER_MFMA>
 __global__ __launch_bounds__(256) void probe(double* out, int iters, double seed) {
+  stamp(0);
   f64x4 acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = f64x4{seed, seed, seed, seed};
   double a = seed + threadIdx.x * 1e-9, b = seed * 0.5;
@@ -30,10 +41,12 @@ __global__ __launch_bounds__(256) void probe(double* out, int iters, double seed
   for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   for (int i = 0; i < 8; ++i) s += v[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  stamp(1);
 }
 
 template <int VALU>
 __global__ __launch_bounds__(256) void probe_valu(double* out, int iters, double seed) {
+  stamp(0);
   double v[16];
   for (int i = 0; i < 16; ++i) v[i] = seed + i;
   double a = seed + threadIdx.x * 1e-9, b = seed * 0.5;
@@ -46,6 +59,7 @@ __global__ __launch_bounds__(256) void probe_valu(double* out, int iters, double
   double s = 0;
   for (int i = 0; i < 16; ++i) s += v[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  stamp(1);
 }
 
 template <typename K>
@@ -60,13 +74,18 @@ static int time_it(const char* name, K kern, int blocks, int iters, double flop_
   CHECK(hipEventSynchronize(e1));
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
   double flops = 5.0 * blocks * 256.0 * iters * flop_per_thread_iter;
-  printf("%-44s blocks/CU=%d  %8.3f ms  %7.2f TFLOP/s\n", name, blocks / 256, ms / 5, flops / (ms * 1e-3) / 1e12);
+  unsigned long long clk[4];
+  CHECK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
+  double ghz = (double)(clk[1] - clk[0]) / (double)(clk[3] - clk[2]) * 0.1;
+  printf("%-44s blocks/CU=%d  %8.3f ms  %7.2f TFLOP/s  clock %.3f GHz  (%.1f%% of 256CUx4x32 flop/clk)\n", name,
+         blocks / 256, ms / 5, flops / (ms * 1e-3) / 1e12, ghz,
+         100.0 * flops / (ms * 1e-3) / (256.0 * 4 * 32 * ghz * 1e9));
   return 0;
 }
 
 int main() {
   double* dout; CHECK(hipMalloc(&dout, sizeof(double) * 256 * 256 * 8));
-  const int iters = 4000;
+  const int iters = 40000;   // ~10-70 ms per launch so the clock settles
   // MFMA 16x16x4 f64 = 2048 flop per wave = 32 flop per thread
   const double mf = 8 * 32.0;
   for (int bpc = 1; bpc <= 2; ++bpc) {
