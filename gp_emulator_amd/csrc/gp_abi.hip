@@ -362,11 +362,12 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.xa_stride = m->xa_stride;
   a.frags_stride = m->frags_stride;
   a.sd_stride = m->sd_stride;
-  const int64_t groups = (M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG * m->n_emulators;
-  if ((M + gpk::kRowsPerWG - 1) / gpk::kRowsPerWG > 0x7fffffffLL)
+  constexpr int kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
+  const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG * m->n_emulators;
+  if ((M + kRowsPerWG - 1) / kRowsPerWG > 0x7fffffffLL)
     return fail(GP_ERR_INVALID, "n_predict too large for one launch");
   // persistent grid: the kernel's occupancy (2 waves per SIMD), grid-stride over work items
-  int64_t grid = (int64_t)ctx->compute_units * gpk::kWGPerCU;
+  int64_t grid = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU;
   if (grid > groups) grid = groups;
   hipError_t e = launch<T>(m->kernel_nb, m->kernel_d, a, (int)grid, ctx->stream);
   if (e != hipSuccess) return fail(GP_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));

@@ -11,7 +11,7 @@ namespace gpk {
 
 template <int D>
 static hipError_t launch_one(const PredictArgs<GP_T>& a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((predict_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL((predict_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(Geo<GP_T>::kThreads), 0, stream, a);
   return hipGetLastError();
 }
 

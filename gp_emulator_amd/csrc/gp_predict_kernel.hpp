@@ -32,23 +32,29 @@ namespace gpk {
 #ifndef GP_WAVES
 #define GP_WAVES 8
 #endif
+#ifndef GP_WAVES_F32
+#define GP_WAVES_F32 12
+#endif
 #ifndef GP_CHUNK
 #define GP_CHUNK 64
 #endif
 #ifndef GP_PREFETCH
-#define GP_PREFETCH 1   // fetch the next item's test rows during the matrix-core phase
+#define GP_PREFETCH 0   // 1: fetch the next item's test rows during the matrix-core phase (A/B: no gain)
 #endif
-// Predict kernel geometry.  8 waves = two per SIMD, all in the same phase: fp64 MFMA and fp64
-// VALU share one pipe on MI355X (tools/mfma_f64_probe.hip), so there is nothing to gain from
-// running a VALU-phase workgroup beside an MFMA-phase one, and partners in the same phase keep
-// the workgroup's waves in step (short barrier waits) while each fragment staged in LDS now
-// feeds 8 waves instead of 4.
-constexpr int kWaves = GP_WAVES;     // waves per workgroup
-constexpr int kThreads = kWaves * 64;
-constexpr int kWGPerCU = 8 / kWaves; // 2 waves per SIMD either way
+// Predict kernel geometry, per compute type.  fp64: 8 waves = two per SIMD (the register
+// budget of the K_* tile), all in the same phase: fp64 MFMA and fp64 VALU share one pipe on
+// MI355X (tools/mfma_f64_probe.hip), so there is nothing to gain from running a VALU-phase
+// workgroup beside an MFMA-phase one, and partners in the same phase keep the workgroup's
+// waves in step (short barrier waits) while each fragment staged in LDS feeds every wave.
 constexpr int kTile = 16;            // test rows per wave tile (MFMA N dimension)
-constexpr int kRowsPerWG = kWaves * kTile;
 constexpr int kChunk = GP_CHUNK;     // A-operand fragments per LDS chunk
+template <typename T> struct Geo {
+  static constexpr int kWaves = sizeof(T) == 8 ? GP_WAVES : GP_WAVES_F32;  // per workgroup
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr int kWavesPerSimd = kWaves >= 8 ? kWaves / 4 : 2;  // launch bound
+  static constexpr int kWGPerCU = kWaves >= 8 ? 1 : 8 / kWaves;
+  static constexpr int kRowsPerWG = kWaves * kTile;
+};
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -188,45 +194,28 @@ __device__ inline T xor_reduce_groups(T v) {
 template <typename T>
 __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int lane) {
   constexpr int kBytes = kChunk * 64 * (int)sizeof(T);
-  constexpr int kPerWave = kBytes / kWaves;       // bytes each wave moves
-  constexpr int kIters = kPerWave / 1024;
-  static_assert(kIters * 1024 * kWaves == kBytes, "chunk must be whole 1 KiB pieces per wave");
-  static_assert(kIters == 4 || kIters == 2 || kIters == 1, "unexpected chunk size");
-  // wave-uniform SGPR source base, 32-bit per-lane VGPR offset (saddr form); the
-  // instruction's immediate offset applies to BOTH the global and the LDS address
-  const char* s = reinterpret_cast<const char*>(src) + wave * kPerWave;
-  const unsigned lds = (unsigned)(uintptr_t)(
-      (__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(dst)) + wave * kPerWave);
-  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds);
+  constexpr int kPieces = kBytes / 1024;          // 1 KiB per wave-instruction
+  constexpr int kWaves = Geo<T>::kWaves;
+  static_assert(kPieces * 1024 == kBytes, "chunk must be whole 1 KiB pieces");
+  // wave-uniform SGPR source base, 32-bit per-lane VGPR offset (saddr form); piece pc goes
+  // to wave (pc mod kWaves)
   const unsigned voff = (unsigned)lane * 16u;
-  if constexpr (kIters == 4) {
-    asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072"
-        :
-        : "s"(m0v), "v"(voff), "s"(s)
-        : "memory");
-  } else if constexpr (kIters == 2) {
-    asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024"
-        :
-        : "s"(m0v), "v"(voff), "s"(s)
-        : "memory");
-  } else {
-    asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
-        "global_load_lds_dwordx4 %1, %2"
-        :
-        : "s"(m0v), "v"(voff), "s"(s)
-        : "memory");
+  const unsigned lds0 = (unsigned)(uintptr_t)(
+      (__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(dst)));
+#pragma unroll
+  for (int pc0 = 0; pc0 < kPieces; pc0 += kWaves) {
+    const int pc = pc0 + wave;
+    if (pc0 + kWaves <= kPieces || pc < kPieces) {
+      const char* s = reinterpret_cast<const char*>(src) + pc * 1024;
+      const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + pc * 1024);
+      asm volatile(
+          "s_mov_b32 m0, %0\n\t"
+          "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
+          "global_load_lds_dwordx4 %1, %2"
+          :
+          : "s"(m0v), "v"(voff), "s"(s)
+          : "memory");
+    }
   }
 }
 // Retire this wave's outstanding LDS-DMA pieces; call right before the barrier that
@@ -234,8 +223,10 @@ __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int 
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T, int D, int NB>
-__global__ __launch_bounds__(kThreads, 2) void predict_kernel(PredictArgs<T> p) {
+__global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predict_kernel(PredictArgs<T> p) {
   typedef Real<T> R;
+  constexpr int kThreads = Geo<T>::kThreads;
+  constexpr int kRowsPerWG = Geo<T>::kRowsPerWG;
   typedef typename R::acc_t acc_t;
   constexpr int NP = 16 * NB;
   constexpr int DS = row_stride(D);
