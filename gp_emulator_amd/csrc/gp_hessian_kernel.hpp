@@ -34,15 +34,91 @@ struct HessianArgs {
 
 // Hessian kernel geometry: 4 waves (one per SIMD) so that the D = 16 instance, which needs
 // ~380 registers, still fits (one wave per SIMD).
-constexpr int hkWaves = 4;
+constexpr int hkWaves = 4;   // two workgroups per CU = two waves per SIMD
 constexpr int hkThreads = hkWaves * 64;
 constexpr int hkRowsPerWG = hkWaves * kTile;
 
+// Rows [lo, hi) of the upper triangle handled in one pass: the pass owns the pairs
+// (d, d2 >= d) with lo <= d < hi.
+__host__ __device__ constexpr int pairs_in_rows(int D, int lo, int hi) {
+  int n = 0;
+  for (int d = lo; d < hi; ++d) n += D - d;
+  return n;
+}
+// Split row so that both passes hold about half of the D(D+1)/2 accumulators.
+__host__ __device__ constexpr int split_row(int D) {
+  int best = 0, bestdiff = 1 << 30;
+  for (int r = 0; r <= D; ++r) {
+    int a = pairs_in_rows(D, 0, r), b = pairs_in_rows(D, r, D);
+    int diff = a > b ? a - b : b - a;
+    if (diff < bestdiff) { bestdiff = diff; best = r; }
+  }
+  return best;
+}
+
+// One pass over the training points accumulating rows [LO, HI) of the Hessian's upper
+// triangle, then the reduction over lane groups and the stores (with mirror elements).
+template <typename T, int D, int LO, int HI>
+__device__ __forceinline__ void hessian_pass(const T* s_xa, const T* s_sd, const T (&t)[D], T b,
+                                             int nb, int g, bool row_ok, int d_actual, T* out) {
+  typedef Real<T> R;
+  constexpr int DS = row_stride(D);
+  constexpr int NP_ = pairs_in_rows(D, LO, HI);
+  T acc[NP_];
+#pragma unroll
+  for (int q = 0; q < NP_; ++q) acc[q] = T(0);
+  T mu = T(0);
+  // one training point per iteration, NOT unrolled: unrolling lets the scheduler keep
+  // several points' delta vectors live on top of the accumulators and spill
+#pragma unroll 1
+  for (int qq = 0; qq < 4 * nb; ++qq) {
+    const int i = 16 * (qq >> 2) + R::own_sub(qq & 3, g);
+    const T* row = &s_xa[i * DS];
+    T dl[D];
+    T r2 = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      dl[d] = row[d] - t[d];
+      r2 = fma(dl[d], dl[d], r2);
+    }
+    const T w = b * R::exp_(T(-0.5) * r2) * row[D];
+    mu += w;
+    int q = 0;
+#pragma unroll
+    for (int d = LO; d < HI; ++d) {
+      const T wd = w * dl[d];
+#pragma unroll
+      for (int d2 = d; d2 < D; ++d2) {
+        acc[q] = fma(wd, dl[d2], acc[q]);
+        ++q;
+      }
+    }
+  }
+  mu = xor_reduce_groups(mu);
+  int q = 0;
+#pragma unroll
+  for (int d = LO; d < HI; ++d) {
+#pragma unroll
+    for (int d2 = d; d2 < D; ++d2) {
+      T v = xor_reduce_groups(acc[q]) * (s_sd[d] * s_sd[d2]);
+      if (d2 == d) v = fma(-(s_sd[d] * s_sd[d]), mu, v);
+      ++q;
+      if (row_ok && d < d_actual && d2 < d_actual) {
+        // element (d, d2) by lane group d & 3, its mirror (d2, d) by group d2 & 3
+        if ((d & 3) == g) out[d * d_actual + d2] = v;
+        if (d2 != d && (d2 & 3) == g) out[d2 * d_actual + d] = v;
+      }
+    }
+  }
+}
+
 template <typename T, int D>
-__global__ __launch_bounds__(hkThreads, 1) void hessian_kernel(HessianArgs<T> p) {
+__global__ __launch_bounds__(hkThreads, 2) void hessian_kernel(HessianArgs<T> p) {
   typedef Real<T> R;
   constexpr int DS = row_stride(D);
   constexpr int NPAIR = D * (D + 1) / 2;
+  // two passes when the accumulators alone would exceed ~half the register file
+  constexpr int kSplit = (NPAIR * (int)sizeof(T) / 4 > 144) ? split_row(D) : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   T* s_xa = reinterpret_cast<T*>(s_raw);
 
@@ -69,57 +145,16 @@ __global__ __launch_bounds__(hkThreads, 1) void hessian_kernel(HessianArgs<T> p)
 #pragma unroll
     for (int d = 0; d < D; ++d)
       t[d] = (d < p.d_actual) ? s_sd[d] * (p.testing[mc * p.d_actual + d] - s_sd[D + d]) : T(0);
-
-    T acc[NPAIR];
-#pragma unroll
-    for (int q = 0; q < NPAIR; ++q) acc[q] = T(0);
-    T mu = T(0);
-
-    // one training point per iteration, NOT unrolled: unrolling lets the scheduler keep
-    // several points' delta vectors live on top of the D(D+1)/2 accumulators and spill
-#pragma unroll 1
-    for (int qq = 0; qq < 4 * p.nb; ++qq) {
-      {
-        const int i = 16 * (qq >> 2) + R::own_sub(qq & 3, g);
-        const T* row = &s_xa[i * DS];
-        T dl[D];
-        T r2 = T(0);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          dl[d] = row[d] - t[d];
-          r2 = fma(dl[d], dl[d], r2);
-        }
-        const T w = b * R::exp_(T(-0.5) * r2) * row[D];
-        mu += w;
-        int q = 0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const T wd = w * dl[d];
-#pragma unroll
-          for (int d2 = d; d2 < D; ++d2) {
-            acc[q] = fma(wd, dl[d2], acc[q]);
-            ++q;
-          }
-        }
-      }
-    }
-    mu = xor_reduce_groups(mu);
-    // reduce over the four lane groups; lane group g then stores rows d == g (mod 4)
-    T* out = p.hess + (m < p.M ? m : 0) * (long long)p.d_actual * p.d_actual;
-    int q = 0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-#pragma unroll
-      for (int d2 = d; d2 < D; ++d2) {
-        T v = xor_reduce_groups(acc[q]) * (s_sd[d] * s_sd[d2]);
-        if (d2 == d) v = fma(-(s_sd[d] * s_sd[d]), mu, v);
-        ++q;
-        if (m < p.M && d < p.d_actual && d2 < p.d_actual) {
-          // element (d, d2) by group d & 3, its mirror (d2, d) by group d2 & 3
-          if ((d & 3) == g) out[d * p.d_actual + d2] = v;
-          if (d2 != d && (d2 & 3) == g) out[d2 * p.d_actual + d] = v;
-        }
-      }
+    T* out = p.hess + mc * (long long)p.d_actual * p.d_actual;
+    const bool row_ok = m < p.M;
+    // D(D+1)/2 fp64 accumulators do not fit the VALU-addressable registers beyond D ~ 11
+    // (the compiler parks the excess in AGPRs and pays two moves per fma); above that the
+    // triangle is done in two passes of ~half the rows each, recomputing the kernel row.
+    if constexpr (kSplit > 0) {
+      hessian_pass<T, D, 0, kSplit>(s_xa, s_sd, t, b, p.nb, g, row_ok, p.d_actual, out);
+      hessian_pass<T, D, kSplit, D>(s_xa, s_sd, t, b, p.nb, g, row_ok, p.d_actual, out);
+    } else {
+      hessian_pass<T, D, 0, D>(s_xa, s_sd, t, b, p.nb, g, row_ok, p.d_actual, out);
     }
   }
 }

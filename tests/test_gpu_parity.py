@@ -281,3 +281,79 @@ def test_multivariate_emulator_gpu(gpu_lib, tmp_path):
     many = mv.predict_many(g["points"], is_gpu=True)
     assert many.shape == (4, 2101)
     assert np.max(np.abs(many - g["fwd"])) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases of the domain
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_far_and_coincident_points(gpu_lib, precision):
+    """Test rows far outside the training cloud: the kernel row underflows to exactly 0, so
+    mu = 0, var = b, deriv = 0 (as the numpy path gives).  Test rows equal to training rows:
+    zero distance, k_ii = b."""
+    g = synthetic_case("c2_n250_d11")
+    t = np.vstack([g["testing"][:5], g["testing"][:3] + 100.0, g["testing"][:3] - 1e4,
+                   g["inputs"][:7]])
+    got = wrap(g, precision, t)
+    ref = gp_oracle.cpu_predict(g["inputs"], g["theta"], g["invQ"], g["invQt"], t)
+    b = np.exp(g["theta"][11])
+    for k in range(5, 11):
+        assert got[0][k] == 0 and np.all(got[2][k] == 0)
+        assert abs(got[1][k] - b) <= 1e-6 * b
+    assert max(errs(ref, got)) <= TOL[precision]
+
+
+def test_nan_row_poisons_only_itself(gpu_lib):
+    g = synthetic_case("c1_n100_d5")
+    t = g["testing"][:200].copy()
+    t[37, 2] = np.nan
+    mu, var, der = wrap(g, np.float64, t)
+    assert np.isnan(mu[37]) and np.isnan(var[37]) and np.all(np.isnan(der[37]))
+    ok = np.ones(200, bool)
+    ok[37] = False
+    assert np.all(np.isfinite(mu[ok])) and np.all(np.isfinite(var[ok])) and np.all(np.isfinite(der[ok]))
+    scale = [np.max(np.abs(g[k])) for k in ("mu", "var", "deriv")]
+    for r, x, s in zip((g["mu"][:200], g["var"][:200], g["deriv"][:200]), (mu, var, der), scale):
+        assert np.max(np.abs(r[ok] - x[ok])) / s <= 1e-10
+
+
+def test_offset_inputs_keep_fp64_parity(gpu_lib):
+    """Inputs with a large common offset (e.g. wavelengths 2000 +- 1): the kernel's
+    expansion h_i + g + x.t is evaluated in centred coordinates, so parity holds."""
+    N, D, M = 120, 6, 500
+    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(77, N, D, M)
+    off = np.array([2000.0, -350.0, 1e4, 0.0, 5.0, 123456.0])
+    inputs, testing = inputs + off, testing + off
+    g = dict(inputs=inputs, theta=theta, invQ=invQ, invQt=invQt, testing=testing)
+    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing)
+    got = wrap(g, np.float64)
+    assert max(errs(ref, got)) <= 1e-10
+
+
+def test_unsupported_shapes_raise(gpu_lib):
+    """Outside the compiled kernel set the library refuses; it never computes elsewhere."""
+    rs = np.random.RandomState(0)
+    N, D = 400, 4
+    g = dict(inputs=rs.rand(N, D), theta=rs.rand(D + 2), invQ=rs.rand(N, N), invQt=rs.rand(N),
+             testing=rs.rand(10, D))
+    with pytest.raises(_lib.GpuPredictError):
+        wrap(g, np.float64)
+    N, D = 20, 17
+    g = dict(inputs=rs.rand(N, D), theta=rs.rand(D + 2), invQ=rs.rand(N, N), invQt=rs.rand(N),
+             testing=rs.rand(10, D))
+    with pytest.raises(_lib.GpuPredictError):
+        wrap(g, np.float64)
+
+
+@pytest.mark.parametrize("N,D", [(16, 2), (17, 4), (33, 7), (112, 8), (113, 9), (129, 12),
+                                 (192, 13), (257, 16), (304, 3), (320, 16)])
+def test_every_kernel_size_class(gpu_lib, N, D):
+    """Walk the (NB, D) dispatch table: block-count boundaries and padded dimensions."""
+    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(900 + N + D, N, D, 321)
+    g = dict(inputs=inputs, theta=theta, invQ=invQ, invQt=invQt, testing=testing)
+    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing)
+    assert max(errs(ref, wrap(g, np.float64))) <= 1e-10
+    assert max(errs(ref, wrap(g, np.float32))) <= 1e-4
+    gp = make_gp(g)
+    h = gp.hessian(testing[:40], is_gpu=True)
+    assert gp_oracle.maxnorm_err(gp_oracle.hessian(inputs, theta, invQt, testing[:40]), h) <= 1e-10
