@@ -67,7 +67,7 @@ def build(force=False, jobs=None, verbose=True, defines=(), lib=None, only_nb=No
 
 def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
     os.makedirs(OBJ, exist_ok=True)
-    stamp = os.path.join(OBJ, "digest.txt")
+    stamp = LIB + ".digest"      # travels with the .so (the object dir does not)
     digest = source_digest() + " ".join(defines) + str(only_nb)
     if (not force and os.path.exists(LIB) and os.path.exists(stamp)
             and open(stamp).read().strip() == digest):
@@ -82,6 +82,9 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
             tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
                                             "-DGP_NB=%d" % nb, "-c",
                                             os.path.join(CSRC, "gp_kernels_tu.hip"), "-o", obj])
+        obj = os.path.join(OBJ, "generic_%s.o" % tname)
+        tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
+                                        os.path.join(CSRC, "gp_generic_tu.hip"), "-o", obj])
         obj = os.path.join(OBJ, "hess_%s.o" % tname)
         tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
                                         os.path.join(CSRC, "gp_hessian_tu.hip"), "-o", obj])

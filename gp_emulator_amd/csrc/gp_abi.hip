@@ -12,10 +12,13 @@
 #include <vector>
 
 #include "gp_dispatch.hpp"
+#include "gp_generic_kernel.hpp"
 #include "gp_hessian_kernel.hpp"
 #include "gp_predict_kernel.hpp"
 
 namespace gpk {
+hipError_t launch_generic_f32(const GenericArgs<float>&, int, hipStream_t);
+hipError_t launch_generic_f64(const GenericArgs<double>&, int, hipStream_t);
 hipError_t launch_hessian_f32(int, const HessianArgs<float>&, int, hipStream_t);
 hipError_t launch_hessian_f64(int, const HessianArgs<double>&, int, hipStream_t);
 #define GP_DECL(nb)                                                                         \
@@ -83,6 +86,10 @@ static const int kKernelNB[] = {
 #undef GP_V
 };
 
+// Kernel choice.  *knb > 0: the fused MFMA kernel predict_kernel<T, *kd, *knb>.
+// *knb == 0: the general-shape kernel (gp_generic_kernel.hpp); *kd is then the padded row
+// dimension (a compiled kernel D when n_inputs <= 16, so the Hessian kernel can share the
+// packed rows; n_inputs itself otherwise).
 static int pick_kernel(int n_train, int n_inputs, int* kd, int* knb) {
   *kd = *knb = -1;
   for (int d : kKernelD)
@@ -90,12 +97,18 @@ static int pick_kernel(int n_train, int n_inputs, int* kd, int* knb) {
   const int need = (n_train + 15) / 16;
   for (int nb : kKernelNB)
     if (nb >= need) { *knb = nb; break; }
-  if (*kd < 0 || *knb < 0)
-    return fail(GP_ERR_UNSUPPORTED,
-                "shape outside the compiled kernel set: n_train=%d (max %d), n_inputs=%d (max %d)",
-                n_train, 16 * GP_MAX_KERNEL_NB, n_inputs, GP_MAX_KERNEL_D);
-  return GP_OK;
+  if (*kd > 0 && *knb > 0) return GP_OK;
+  if (n_train <= gpk::gkMaxN && n_inputs <= gpk::gkMaxD) {
+    if (*kd < 0) *kd = n_inputs;
+    *knb = 0;
+    return GP_OK;
+  }
+  return fail(GP_ERR_UNSUPPORTED,
+              "shape outside the compiled kernel set: n_train=%d (max %d), n_inputs=%d (max %d)",
+              n_train, gpk::gkMaxN, n_inputs, gpk::gkMaxD);
 }
+static inline int rows_padded(int n_train, int knb) { return knb > 0 ? 16 * knb : 16 * ((n_train + 15) / 16); }
+static inline int row_stride_of(int kd) { return gpk::row_stride(kd); }
 
 // ------------------------------------------------------------------------------------
 // host-side packing (double arithmetic, one rounding to T at the end)
@@ -111,8 +124,8 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
   int kd, knb;
   int rc = pick_kernel(N, D, &kd, &knb);
   if (rc) return rc;
-  const int DS = gpk::row_stride(kd);
-  const int NP = 16 * knb;
+  const int DS = row_stride_of(kd);
+  const int NP = rows_padded(N, knb);
   // sqrt(e_d): the reference scales both point sets by sqrt(expX[:D]) before cdist
   // (GaussianProcess.py:232-233; the CUDA path takes the sqrt on the host too,
   // _gpu_predict.cpp:135-140).  Both sets are also shifted by the training mean c_d first:
@@ -149,6 +162,10 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
   // with S'_IJ = M_IJ + M_JI^T for I < J and M_JJ on the diagonal, so that
   //   k^T M k = sum_J sum_{I<=J} k_I^T S'_IJ k_J        for ANY matrix M.
   if (!invQ) return GP_OK;   // Hessian-only model: no variance operand
+  if (knb == 0) {            // general-shape kernel: invQ as given
+    for (size_t q = 0; q < (size_t)N * N; ++q) frags[q] = invQ[q];
+    return GP_OK;
+  }
   const int nfp = gpk::frag_count_padded(knb, gpk::kChunk);
   std::memset(frags, 0, sizeof(T) * (size_t)nfp * 64);
   for (int J = 0; J < knb; ++J)
@@ -271,8 +288,10 @@ int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kern
   if (rc) return rc;
   if (kernel_d) *kernel_d = kd;
   if (kernel_nb) *kernel_nb = knb;
-  if (xa_len) *xa_len = (int64_t)16 * knb * gpk::row_stride(kd);
-  if (frags_len) *frags_len = (int64_t)gpk::frag_count_padded(knb, gpk::kChunk) * 64;
+  if (xa_len) *xa_len = (int64_t)rows_padded(n_train, knb) * row_stride_of(kd);
+  if (frags_len)
+    *frags_len = knb > 0 ? (int64_t)gpk::frag_count_padded(knb, gpk::kChunk) * 64
+                         : (int64_t)n_train * n_train;
   return GP_OK;
 }
 
@@ -345,8 +364,45 @@ static int model_create(gp_ctx* ctx, int E, const T* expX, const T* inputs, cons
 }
 
 template <typename T>
+static hipError_t launch_generic(const gpk::GenericArgs<T>& a, int grid, hipStream_t s);
+template <>
+hipError_t launch_generic<float>(const gpk::GenericArgs<float>& a, int grid, hipStream_t s) {
+  return gpk::launch_generic_f32(a, grid, s);
+}
+template <>
+hipError_t launch_generic<double>(const gpk::GenericArgs<double>& a, int grid, hipStream_t s) {
+  return gpk::launch_generic_f64(a, grid, s);
+}
+
+template <typename T>
 static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_mu,
                           void* d_var, void* d_deriv, int64_t M, int layout) {
+  if (m->kernel_nb == 0) {   // general-shape kernel
+    if (m->n_emulators != 1)
+      return fail(GP_ERR_UNSUPPORTED, "batched emulators need n_train <= %d and n_inputs <= %d",
+                  16 * GP_MAX_KERNEL_NB, GP_MAX_KERNEL_D);
+    gpk::GenericArgs<T> g;
+    g.xa = (const T*)m->d_xa;
+    g.invQ = (const T*)m->d_frags;
+    g.sd = (const T*)m->d_sd;
+    g.testing = (const T*)d_testing;
+    g.mu = (T*)d_mu;
+    g.var = (T*)d_var;
+    g.deriv = (T*)d_deriv;
+    g.M = M;
+    g.N = m->n_train;
+    g.D = m->n_inputs;
+    g.ds = row_stride_of(m->kernel_d);
+    g.acol = m->kernel_d;
+    g.dk = m->kernel_d;
+    g.deriv_row_major = layout == GP_DERIV_ROWMAJOR;
+    int64_t tiles = (M + 15) / 16;
+    int64_t grid = (int64_t)ctx->compute_units * 4;
+    if (grid > tiles) grid = tiles;
+    hipError_t e = launch_generic<T>(g, (int)grid, ctx->stream);
+    if (e != hipSuccess) return fail(GP_ERR_HIP, "generic kernel launch: %s", hipGetErrorString(e));
+    return GP_OK;
+  }
   gpk::PredictArgs<T> a;
   a.xa = (const T*)m->d_xa;
   a.frags = (const T*)m->d_frags;
@@ -395,6 +451,10 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.M = M;
   a.d_actual = m->n_inputs;
   a.nb = (m->n_train + 15) / 16;     // the loop over training points is a run-time loop
+  if (m->n_inputs > GP_MAX_KERNEL_D)
+    return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
+  if (sizeof(T) * (16 * (size_t)a.nb * gpk::row_stride(m->kernel_d) + 2 * m->kernel_d) > 160 * 1024)
+    return fail(GP_ERR_UNSUPPORTED, "training set too large for the hessian kernel's LDS image");
   const int64_t groups = (M + gpk::hkRowsPerWG - 1) / gpk::hkRowsPerWG;
   int64_t grid = (int64_t)ctx->compute_units * 2;
   if (grid > groups) grid = groups;

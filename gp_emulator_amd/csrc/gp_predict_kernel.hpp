@@ -262,7 +262,9 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
     for (int d = 0; d < D; ++d) dst[d] = (d < p.d_actual) ? p.testing[mc_ * p.d_actual + d] : T(0);
   };
   T traw[D];
+#if GP_PREFETCH
   if (e < p.n_emulators) load_rows(grp, traw);
+#endif
 
   for (; e < p.n_emulators;) {
     if (e != cur_e) {   // (re)load this emulator's training rows and scalars
@@ -290,6 +292,9 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
     // one fma per (training point, dimension) for the kernel row and one for the gradient
     // sum  G_d = sum_i w_i x''_id,  deriv_d = sqrt(e_d) (G_d - t''_d mu).  Centring on the
     // training mean c keeps |x''|, |t''| (hence the cancellation in h + g + x.t) small.
+#if !GP_PREFETCH
+    load_rows(grp, traw);
+#endif
     T t[D];
     T gm = T(0);
 #pragma unroll
@@ -385,9 +390,6 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 
     e = e_next;
     grp = grp_next;
-#if !GP_PREFETCH
-    if (e < p.n_emulators) load_rows(grp, traw);
-#endif
   }
 }
 

@@ -106,11 +106,24 @@ def test_packed_fragments_reproduce_quadratic_form(name, dtype):
     assert gp_oracle.maxnorm_err(o_der, grad) < tol
 
 
-def test_pack_rejects_unsupported_shapes():
+def test_pack_kernel_choice_and_unsupported_shapes():
+    """N <= 320 and D <= 16: fused MFMA kernel; up to N = 1024, D = 64: general-shape kernel
+    (kernel_nb == 0, invQ kept as given); beyond: refused."""
+    pk = _lib.pack_model(np.ones(13), np.zeros((250, 11)), np.zeros(250), np.zeros((250, 250)))
+    assert (pk["kernel_d"], pk["kernel_nb"]) == (11, 16)
+    pk = _lib.pack_model(np.ones(12), np.zeros((300, 10)), np.zeros(300), np.zeros((300, 300)))
+    assert (pk["kernel_d"], pk["kernel_nb"]) == (10, 19)
+    rs = np.random.RandomState(3)
+    q = rs.rand(400, 400)
+    pk = _lib.pack_model(np.ones(6), rs.rand(400, 4), np.zeros(400), q)
+    assert pk["kernel_nb"] == 0 and pk["kernel_d"] == 4
+    assert np.array_equal(pk["frags"].reshape(400, 400), q)
+    pk = _lib.pack_model(np.ones(40), np.zeros((10, 38)), np.zeros(10), np.zeros((10, 10)))
+    assert pk["kernel_nb"] == 0 and pk["kernel_d"] == 38
     with pytest.raises(_lib.GpuPredictError):
-        _lib.pack_model(np.ones(40), np.zeros((10, 38)), np.zeros(10), np.zeros((10, 10)))
+        _lib.pack_model(np.ones(72), np.zeros((10, 70)), np.zeros(10), np.zeros((10, 10)))
     with pytest.raises(_lib.GpuPredictError):
-        _lib.pack_model(np.ones(4), np.zeros((5000, 2)), np.zeros(5000), np.zeros((5000, 5000)))
+        _lib.pack_model(np.ones(4), np.zeros((1100, 2)), np.zeros(1100), np.zeros((1100, 1100)))
 
 
 BLOCK_CASES = [(250000, 100000), (200000, 100000), (1000, 200000), (200001, 100000),

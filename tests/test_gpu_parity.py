@@ -331,18 +331,38 @@ def test_offset_inputs_keep_fp64_parity(gpu_lib):
 
 
 def test_unsupported_shapes_raise(gpu_lib):
-    """Outside the compiled kernel set the library refuses; it never computes elsewhere."""
+    """Outside every compiled kernel the library refuses; it never computes elsewhere."""
     rs = np.random.RandomState(0)
-    N, D = 400, 4
-    g = dict(inputs=rs.rand(N, D), theta=rs.rand(D + 2), invQ=rs.rand(N, N), invQt=rs.rand(N),
-             testing=rs.rand(10, D))
-    with pytest.raises(_lib.GpuPredictError):
-        wrap(g, np.float64)
-    N, D = 20, 17
-    g = dict(inputs=rs.rand(N, D), theta=rs.rand(D + 2), invQ=rs.rand(N, N), invQt=rs.rand(N),
-             testing=rs.rand(10, D))
-    with pytest.raises(_lib.GpuPredictError):
-        wrap(g, np.float64)
+    for N, D in ((1100, 4), (20, 65)):
+        g = dict(inputs=rs.rand(N, D), theta=rs.rand(D + 2), invQ=rs.rand(N, N), invQt=rs.rand(N),
+                 testing=rs.rand(10, D))
+        with pytest.raises(_lib.GpuPredictError):
+            wrap(g, np.float64)
+
+
+@pytest.mark.parametrize("N,D", [(321, 16), (400, 4), (20, 17), (640, 30), (1024, 64)])
+def test_general_shape_kernel(gpu_lib, N, D):
+    """Shapes beyond the fused MFMA kernel set (N > 320 or D > 16) run on the general-shape
+    kernel: same boundary, same tolerances."""
+    M = 203
+    rs = np.random.RandomState(N + D)
+    inputs, testing = rs.random_sample((N, D)), rs.random_sample((M, D))
+    theta = rs.random_sample(D + 2) - (np.log(D / 8.0) if D > 16 else 0.0)   # keep k_i away from 0
+    invQ, invQt = rs.random_sample((N, N)), rs.random_sample(N)
+    g = dict(inputs=inputs, theta=theta, invQ=invQ, invQt=invQt, testing=testing)
+    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing)
+    for precision in (np.float64, np.float32):
+        got = wrap(g, precision)
+        assert max(errs(ref, got)) <= TOL[precision], (precision, errs(ref, got))
+    gp = make_gp(g)
+    full = gp.predict(testing, is_gpu=True)
+    assert max(errs(ref, full)) <= 1e-10
+    if D <= 16:
+        h = gp.hessian(testing[:30], is_gpu=True)
+        assert gp_oracle.maxnorm_err(gp_oracle.hessian(inputs, theta, invQt, testing[:30]), h) <= 1e-10
+    else:
+        with pytest.raises(_lib.GpuPredictError):
+            gp.hessian(testing[:4], is_gpu=True)
 
 
 @pytest.mark.parametrize("N,D", [(16, 2), (17, 4), (33, 7), (112, 8), (113, 9), (129, 12),
