@@ -166,7 +166,7 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
     for (size_t q = 0; q < (size_t)N * N; ++q) frags[q] = invQ[q];
     return GP_OK;
   }
-  const int nfp = gpk::frag_count_padded(knb, gpk::kChunk);
+  const int nfp = gpk::frag_count_padded(knb, gpk::Geo<T>::kChunk);
   std::memset(frags, 0, sizeof(T) * (size_t)nfp * 64);
   for (int J = 0; J < knb; ++J)
     for (int I = 0; I <= J; ++I)
@@ -282,7 +282,6 @@ int gp_ctx_device_info(gp_ctx* ctx, int* compute_units, int64_t* hbm_bytes, char
 
 int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,
                   int64_t* xa_len, int64_t* frags_len) {
-  (void)dtype;
   int kd, knb;
   int rc = pick_kernel(n_train, n_inputs, &kd, &knb);
   if (rc) return rc;
@@ -290,7 +289,8 @@ int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kern
   if (kernel_nb) *kernel_nb = knb;
   if (xa_len) *xa_len = (int64_t)rows_padded(n_train, knb) * row_stride_of(kd);
   if (frags_len)
-    *frags_len = knb > 0 ? (int64_t)gpk::frag_count_padded(knb, gpk::kChunk) * 64
+    *frags_len = knb > 0 ? (int64_t)gpk::frag_count_padded(
+                               knb, dtype == GP_F64 ? gpk::Geo<double>::kChunk : gpk::Geo<float>::kChunk) * 64
                          : (int64_t)n_train * n_train;
   return GP_OK;
 }
@@ -318,7 +318,7 @@ static int model_create(gp_ctx* ctx, int E, const T* expX, const T* inputs, cons
   if (E <= 0) return fail(GP_ERR_INVALID, "n_emulators must be positive");
   int kd, knb;
   int64_t xa_len, fr_len;
-  int rc = gp_pack_sizes(0, N, D, &kd, &knb, &xa_len, &fr_len);
+  int rc = gp_pack_sizes(sizeof(T) == 8 ? GP_F64 : GP_F32, N, D, &kd, &knb, &xa_len, &fr_len);
   if (rc) return rc;
   const int64_t sd_len = 2 * kd + 1;
   if (!invQ) fr_len = 0;

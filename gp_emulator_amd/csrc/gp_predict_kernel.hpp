@@ -38,6 +38,9 @@ namespace gpk {
 #ifndef GP_CHUNK
 #define GP_CHUNK 64
 #endif
+#ifndef GP_CHUNK_F32
+#define GP_CHUNK_F32 128   // fp32 MFMAs take half the time: same cover for the LDS-DMA latency
+#endif
 #ifndef GP_PREFETCH
 #define GP_PREFETCH 0   // 1: fetch the next item's test rows during the matrix-core phase (A/B: no gain)
 #endif
@@ -47,13 +50,14 @@ namespace gpk {
 // workgroup beside an MFMA-phase one, and partners in the same phase keep the workgroup's
 // waves in step (short barrier waits) while each fragment staged in LDS feeds every wave.
 constexpr int kTile = 16;            // test rows per wave tile (MFMA N dimension)
-constexpr int kChunk = GP_CHUNK;     // A-operand fragments per LDS chunk
 template <typename T> struct Geo {
   static constexpr int kWaves = sizeof(T) == 8 ? GP_WAVES : GP_WAVES_F32;  // per workgroup
   static constexpr int kThreads = kWaves * 64;
   static constexpr int kWavesPerSimd = kWaves >= 8 ? kWaves / 4 : 2;  // launch bound
   static constexpr int kWGPerCU = kWaves >= 8 ? 1 : 8 / kWaves;
   static constexpr int kRowsPerWG = kWaves * kTile;
+  // A-operand fragments per LDS chunk (double-buffered: 2 x kChunk x 64 reals of LDS)
+  static constexpr int kChunk = sizeof(T) == 8 ? GP_CHUNK : GP_CHUNK_F32;
 };
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -77,6 +81,7 @@ template <> struct Real<double> {
   // phase A in expansion form (k = exp(h_i + g + x''.t''), 2 fma per point and dimension):
   // the cancellation costs ~|x''|^2 ulps of 1e-16, far inside the 1e-10 fp64 bar
   static constexpr bool kExpand = true;
+  static constexpr int kGroup = 1;     // training points per software-pipelined group
   // row (within a 16-block) of C/D register r for lane group g:
   // v_mfma_f64_16x16x4_f64: row = g + 4 r   (cdna_hip_programming.md section 3)
   __host__ __device__ static constexpr int own_sub(int r, int g) { return 4 * r + g; }
@@ -115,6 +120,10 @@ template <> struct Real<float> {
   // in fp32 the expansion's cancellation would cost ~4x accuracy on ill-conditioned real
   // emulators, and fp32 VALU ops are half the price of fp64 ones
   static constexpr bool kExpand = false;
+#ifndef GP_GROUP_F32
+#define GP_GROUP_F32 2
+#endif
+  static constexpr int kGroup = GP_GROUP_F32;
   // v_mfma_f32_16x16x4_f32: row = 4 g + r
   __host__ __device__ static constexpr int own_sub(int r, int g) { return 4 * g + r; }
   __device__ static inline acc_t mfma(float a, float b, acc_t c) {
@@ -193,6 +202,7 @@ __device__ inline T xor_reduce_groups(T v) {
 // own uses (none in this kernel), so the asm sets it without listing it as a clobber.
 template <typename T>
 __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int lane) {
+  constexpr int kChunk = Geo<T>::kChunk;
   constexpr int kBytes = kChunk * 64 * (int)sizeof(T);
   constexpr int kPieces = kBytes / 1024;          // 1 KiB per wave-instruction
   constexpr int kWaves = Geo<T>::kWaves;
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
   constexpr int NP = 16 * NB;
   constexpr int DS = row_stride(D);
   constexpr int NF = frag_count(NB);
+  constexpr int kChunk = Geo<T>::kChunk;
   constexpr int NCH = (NF + kChunk - 1) / kChunk;
 
   __shared__ __attribute__((aligned(16))) T s_xa[NP * DS];
@@ -310,33 +321,57 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 #pragma unroll
     for (int d = 0; d < D; ++d) ga[d] = T(0);
 
-    static_for<4 * NB>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      const int i = own_index<T>(q >> 2, q & 3, g);
-      const T* row = &s_xa[i * DS];
-      T x[D];
+    // Training points are handled in groups of R::kGroup whose stages (LDS reads +
+    // distance, exp, gradient update) are written out stage by stage, so that within a
+    // group the loads are in flight together and the serial distance chains interleave.
+    // fp64 has no registers to spare for that (kGroup = 1); fp32 does.
+    constexpr int GP = R::kGroup;
+    static_assert((4 * NB) % GP == 0, "group size must divide the points per lane");
+    static_for<4 * NB / GP>([&](auto qc) {
+      constexpr int q0 = decltype(qc)::value * GP;
+      T x[GP][D];
+      T al[GP];
+      T k[GP];
+      // stage 1: rows -> registers, exponent argument
 #pragma unroll
-      for (int d = 0; d < D; ++d) x[d] = row[d];
-      T k;
-      if constexpr (R::kExpand) {
-        T arg = row[D + 1] + gm;
+      for (int u = 0; u < GP; ++u) {
+        const int q = q0 + u;
+        const int i = own_index<T>(q >> 2, q & 3, g);
+        const T* row = &s_xa[i * DS];
 #pragma unroll
-        for (int d = 0; d < D; ++d) arg = fma(x[d], t[d], arg);
-        k = R::exp_(arg);
-      } else {
-        T r2 = T(0);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          x[d] -= t[d];
-          r2 = fma(x[d], x[d], r2);
-        }
-        k = b * R::exp_(T(-0.5) * r2);
+        for (int d = 0; d < D; ++d) x[u][d] = row[d];
+        al[u] = row[D];
+        if constexpr (R::kExpand) k[u] = row[D + 1] + gm;
       }
-      kv[q] = k;
-      const T w = k * row[D];
-      mu += w;
 #pragma unroll
-      for (int d = 0; d < D; ++d) ga[d] = fma(w, x[d], ga[d]);
+      for (int u = 0; u < GP; ++u) {
+        if constexpr (R::kExpand) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) k[u] = fma(x[u][d], t[d], k[u]);
+        } else {
+          T r2 = T(0);
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            x[u][d] -= t[d];
+            r2 = fma(x[u][d], x[u][d], r2);
+          }
+          k[u] = T(-0.5) * r2;
+        }
+      }
+      // stage 2: kernel values
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        k[u] = R::kExpand ? R::exp_(k[u]) : b * R::exp_(k[u]);
+        kv[q0 + u] = k[u];
+      }
+      // stage 3: mean and gradient sums
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        const T w = k[u] * al[u];
+        mu += w;
+#pragma unroll
+        for (int d = 0; d < D; ++d) ga[d] = fma(w, x[u][d], ga[d]);
+      }
     });
     mu = xor_reduce_groups(mu);
 #pragma unroll
