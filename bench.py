@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "mv"],
                     help="c2 = the metric's config (default); c3/c4/c5 = the other BASELINE configs")
     ap.add_argument("--n-test", type=int, default=0, help="rows per GPU per step (0 = workload default)")
     ap.add_argument("--emulators", type=int, default=2101, help="emulators in the c3 batch")
@@ -98,8 +98,70 @@ def flop_per_point(N, D, kind):
     return 3 * N * D + 3 * N + 2 * N + (2 * N * N + 2 * N + 1) + (3 * N * D + D)
 
 
+def bench_reconstruct(a):
+    """--workload mv: the MultivariateEmulator reconstruction for
+    M = 1e5 test rows, 12 PCs, D = 10, 2101 bands: fwd (M, 2101) and Jacobian (M, 10, 2101)
+    from per-PC outputs resident in HBM.  HBM-write-bound: 8 B written per 12 fma."""
+    from gp_emulator_amd import _lib
+    ctx = _lib.Context(0)
+    info = ctx.device_info()
+    M, P, D, B = a.n_test or 100000, 12, 10, 2101
+    dt = np.float64 if a.precision == "f64" else np.float32
+    isz = np.dtype(dt).itemsize
+    rs = np.random.RandomState(3)
+    basis = rs.standard_normal((P, B)).astype(dt)
+    mu = rs.standard_normal((P, M)).astype(dt)
+    grad = rs.standard_normal((P, M * D)).astype(dt)
+    d_b, d_mu, d_g = ctx.to_device(basis), ctx.to_device(mu), ctx.to_device(grad)
+    d_f, d_j = ctx.malloc(M * B * isz), ctx.malloc(M * D * B * isz)
+
+    def step():
+        ctx.reconstruct_device(dt, d_b, d_mu, d_f, M, P, B)
+        ctx.reconstruct_device(dt, d_b, d_g, d_j, M * D, P, B)
+    for _ in range(a.warmup):
+        step()
+    ctx.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    t0 = time.perf_counter()
+    ctx.record(e0)
+    for _ in range(a.steps):
+        step()
+    ctx.record(e1)
+    ctx.synchronize()
+    dt_wall = time.perf_counter() - t0
+    kern_s = ctx.elapsed_ms(e0, e1) * 1e-3 / a.steps
+    idx = rs.choice(M, 64, replace=False)
+    got = ctx.to_host(d_f, (M, B), dt)[idx]
+    ref = mu.astype(np.float64)[:, idx].T @ basis.astype(np.float64)
+    err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+    tol = 1e-12 if a.precision == "f64" else 1e-5
+    if not err <= tol:
+        raise SystemExit("reconstruct parity failed: %g" % err)
+    bytes_step = (M * B + M * D * B) * isz            # written; coefficients are 0.06 % of it
+    gbps = bytes_step / kern_s / 1e9
+    out = {"metric": "test rows/sec for MultivariateEmulator reconstruction (fwd + Jacobian), 12 PCs, D=10, 2101 bands",
+           "value": a.steps * M / dt_wall, "unit": "test-rows/s", "n_gpus": 1, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": dt_wall / a.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+           "config": {"workload": "MultivariateEmulator reconstruction (gp_emulator/multivariate_gp.py:214-218 "
+                                  "for M rows): n_test=%d, n_pcs=12, n_inputs=10, n_bands=2101; per-PC means "
+                                  "and gradients resident in HBM" % M,
+                      "device": info["name"]},
+           "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": gbps / PEAK_HBM_GBPS, "traffic": None,
+                        "kernel": "reconstruct_kernel<%s,12> x2" % ("double" if a.precision == "f64" else "float"),
+                        "kernel_ms": kern_s * 1e3, "bytes_per_row": (B + D * B) * isz},
+           "parity": {"e_fwd": err, "tol": tol, "checked_rows": 64}}
+    print(json.dumps(out), flush=True)
+    for p_ in (d_b, d_mu, d_g, d_f, d_j):
+        ctx.free(p_)
+    return out
+
+
 def main():
     a = parse()
+    if a.workload == "mv":
+        return bench_reconstruct(a)
     from gp_emulator_amd import _lib, multi_gpu
     from oracle import gp_oracle  # inputs recipe, parity spot check, cpu_baseline leg only
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "gp_hessian_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
     "gp_hessian_f64": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_hessian_f32": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
+    "gp_reconstruct_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int]),
     "gp_pack_sizes": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                               ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "gp_pack_model_f64": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),
@@ -171,6 +172,12 @@ class Context:
         if out.nbytes:
             check(self.lib.gp_memcpy_d2h(self.h, _ptr(out), dptr, out.nbytes), "gp_memcpy_d2h")
         return out
+
+    def reconstruct_device(self, dtype, d_basis, d_coef, d_out, n_rows, n_pcs, n_bands):
+        """out[r][band] = sum_p coef[p][r] * basis[p][band] on the device (asynchronous)."""
+        code = GP_F64 if np.dtype(dtype) == np.float64 else GP_F32
+        check(self.lib.gp_reconstruct_device(self.h, code, d_basis, d_coef, d_out, int(n_rows),
+                                             int(n_pcs), int(n_bands)), "gp_reconstruct_device")
 
     # ---- events -----------------------------------------------------------------
     def event(self):

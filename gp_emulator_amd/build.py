@@ -88,6 +88,8 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
         obj = os.path.join(OBJ, "hess_%s.o" % tname)
         tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
                                         os.path.join(CSRC, "gp_hessian_tu.hip"), "-o", obj])
+    tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_reconstruct_tu.hip"),
+                                           "-o", os.path.join(OBJ, "reconstruct.o")])
     abi_obj = os.path.join(OBJ, "gp_abi.o")
     tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_abi.hip"), "-o", abi_obj])
     # biggest kernels first so the pool drains evenly

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -15,8 +16,11 @@
 #include "gp_generic_kernel.hpp"
 #include "gp_hessian_kernel.hpp"
 #include "gp_predict_kernel.hpp"
+#include "gp_reconstruct_kernel.hpp"
 
 namespace gpk {
+hipError_t launch_reconstruct_f32(const ReconArgs<float>&, int wide, int cus, hipStream_t);
+hipError_t launch_reconstruct_f64(const ReconArgs<double>&, int wide, int cus, hipStream_t);
 hipError_t launch_generic_f32(const GenericArgs<float>&, int, hipStream_t);
 hipError_t launch_generic_f64(const GenericArgs<double>&, int, hipStream_t);
 hipError_t launch_hessian_f32(int, const HessianArgs<float>&, int, hipStream_t);
@@ -665,6 +669,32 @@ int gp_predict_rows_f32(gp_ctx* ctx, const float* expX, const float* inputs, con
                         float* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
   return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
                              n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
+}
+
+int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const void* d_coef,
+                          void* d_out, int64_t n_rows, int n_pcs, int n_bands) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  if (n_rows < 0 || n_pcs <= 0 || n_bands <= 0) return fail(GP_ERR_INVALID, "bad sizes");
+  if (n_pcs > 16) return fail(GP_ERR_UNSUPPORTED, "reconstruction kernels are compiled for n_pcs <= 16");
+  if (n_rows == 0) return GP_OK;
+  if (!d_basis || !d_coef || !d_out) return fail(GP_ERR_INVALID, "null device pointer");
+  if (dtype != GP_F32 && dtype != GP_F64) return fail(GP_ERR_INVALID, "bad dtype %d", dtype);
+  HIP_TRY(hipSetDevice(ctx->device));
+  // geometry: rows that one 512-thread workgroup can cover whole (and that a 256-thread one
+  // cannot) use the wide form; GP_RECON_WIDE=0/1 overrides for A/B measurements
+  const int vec = dtype == GP_F64 ? 2 : 4;
+  int wide = (n_bands > 256 * 2 * vec && n_bands <= 512 * 3 * vec) ? 1 : 0;
+  if (const char* ev = getenv("GP_RECON_WIDE")) wide = atoi(ev) != 0;
+  hipError_t e;
+  if (dtype == GP_F64) {
+    gpk::ReconArgs<double> a{(const double*)d_basis, (const double*)d_coef, (double*)d_out, n_rows, n_pcs, n_bands};
+    e = gpk::launch_reconstruct_f64(a, wide, ctx->compute_units, ctx->stream);
+  } else {
+    gpk::ReconArgs<float> a{(const float*)d_basis, (const float*)d_coef, (float*)d_out, n_rows, n_pcs, n_bands};
+    e = gpk::launch_reconstruct_f32(a, wide, ctx->compute_units, ctx->stream);
+  }
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "reconstruct kernel launch: %s", hipGetErrorString(e));
+  return GP_OK;
 }
 
 int gp_malloc(gp_ctx* ctx, int64_t bytes, void** dptr) {

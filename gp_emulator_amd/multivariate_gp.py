@@ -108,14 +108,45 @@ class MultivariateEmulator(object):
             return fwd.squeeze(), deriv
         return fwd.squeeze()
 
-    def predict_many(self, Y, is_gpu=True, precision=np.float64):
+    def predict_many(self, Y, is_gpu=True, precision=np.float64, do_deriv=False):
         """Beyond the reference (whose predict breaks for more than one row, SURVEY.md
-        section 3.3): reconstructed outputs ``(M, N_full)`` for M input rows.  On the GPU the
-        n_pcs emulators run as ONE batched launch over the shared rows."""
+        section 3.3): reconstructed outputs ``(M, N_full)`` -- and with ``do_deriv`` the
+        Jacobians ``(M, N_params, N_full)`` -- for M input rows.  On the GPU the n_pcs
+        emulators run as ONE batched launch over the shared rows and the reconstruction
+        ``sum_pc mu_pc * basis_pc`` is a second kernel on the resident outputs; only the
+        reconstructed arrays cross PCIe."""
         Y = np.atleast_2d(Y)
-        if is_gpu:
-            from . import perband
-            mu, _, _ = perband.predict_bands(self.emulators, Y, precision)
-        else:
-            mu = np.stack([gp.predict(Y)[0] for gp in self.emulators])
-        return mu.T @ self.basis_functions
+        M, D = Y.shape
+        B = self.basis_functions.shape[1]
+        if not is_gpu:
+            out = [gp.predict(Y) for gp in self.emulators]
+            fwd = np.stack([o[0] for o in out]).T @ self.basis_functions
+            if not do_deriv:
+                return fwd
+            grads = np.stack([o[2] for o in out])                  # (P, M, D)
+            return fwd, np.einsum("pmd,pb->mdb", grads, self.basis_functions)
+        from . import _lib, perband
+        dt = np.dtype(precision)
+        batch = perband.make_batch(self.emulators, dt)
+        ctx = batch.ctx
+        P, isz = self.n_pcs, dt.itemsize
+        bufs = []
+        try:
+            d_y = ctx.to_device(np.ascontiguousarray(Y, dtype=dt)); bufs.append(d_y)
+            d_mu = ctx.malloc(P * M * isz); bufs.append(d_mu)
+            d_var = ctx.malloc(P * M * isz); bufs.append(d_var)
+            d_der = ctx.malloc(P * M * D * isz); bufs.append(d_der)
+            d_basis = ctx.to_device(np.ascontiguousarray(self.basis_functions, dtype=dt)); bufs.append(d_basis)
+            batch.predict_device(d_y, d_mu, d_var, d_der, M, _lib.GP_DERIV_ROWMAJOR)
+            d_fwd = ctx.malloc(M * B * isz); bufs.append(d_fwd)
+            ctx.reconstruct_device(dt, d_basis, d_mu, d_fwd, M, P, B)
+            fwd = ctx.to_host(d_fwd, (M, B), dt)
+            if not do_deriv:
+                return fwd
+            d_jac = ctx.malloc(M * D * B * isz); bufs.append(d_jac)
+            ctx.reconstruct_device(dt, d_basis, d_der, d_jac, M * D, P, B)
+            return fwd, ctx.to_host(d_jac, (M, D, B), dt)
+        finally:
+            for b in bufs:
+                ctx.free(b)
+            batch.close()

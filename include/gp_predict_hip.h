@@ -149,6 +149,16 @@ int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const fl
                    const float* testing, float* hess,
                    int64_t n_predict, int n_train, int n_inputs, int theta_size);
 
+/* ---- multivariate reconstruction ----------------------------------------------------------
+ * out[r][band] = sum_p coef[p][r] * basis[p][band]  for r < n_rows, device pointers, dtype =
+ * GP_F32 / GP_F64, asynchronous on the context's stream, n_pcs <= 16.  With coef = the mean of
+ * a batched predict ([n_pcs][M]) this is MultivariateEmulator.predict's reconstruction
+ * (gp_emulator/multivariate_gp.py:214-216) for M rows at once; with coef = its gradient
+ * ([n_pcs][M*D], rows r = (m, d)) it is the Jacobian (:218).  The reference does both on the
+ * host for one test row per call. */
+int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const void* d_coef,
+                          void* d_out, int64_t n_rows, int n_pcs, int n_bands);
+
 /* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  xa and frags
  * are sized by gp_pack_sizes; sd takes 2*kernel_d + 1 reals (sqrt(e_d), the centre c_d, b);
  * used by the CPU tests to check the fragment layout. */

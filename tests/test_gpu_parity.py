@@ -281,6 +281,39 @@ def test_multivariate_emulator_gpu(gpu_lib, tmp_path):
     many = mv.predict_many(g["points"], is_gpu=True)
     assert many.shape == (4, 2101)
     assert np.max(np.abs(many - g["fwd"])) <= 1e-6
+    fwd, jac = mv.predict_many(g["points"], is_gpu=True, do_deriv=True)
+    assert jac.shape == (4, 10, 2101)
+    assert np.array_equal(fwd, many)
+    assert np.max(np.abs(jac - g["jac"])) / np.max(np.abs(g["jac"])) <= 1e-5
+    # device reconstruction == host matmul on the same per-PC outputs, many rows
+    rs = np.random.RandomState(2)
+    lo, hi = mv.y_train.min(axis=0), mv.y_train.max(axis=0)
+    Y = lo + (hi - lo) * rs.random_sample((777, 10))
+    f_gpu, j_gpu = mv.predict_many(Y, is_gpu=True, do_deriv=True)
+    f_cpu, j_cpu = mv.predict_many(Y, is_gpu=False, do_deriv=True)
+    assert np.max(np.abs(f_gpu - f_cpu)) / np.max(np.abs(f_cpu)) <= 1e-9
+    assert np.max(np.abs(j_gpu - j_cpu)) / np.max(np.abs(j_cpu)) <= 1e-9
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("P,B,R", [(12, 2101, 1000), (1, 7, 3), (16, 1024, 129), (5, 1025, 128), (9, 300, 257)])
+def test_reconstruct_kernel(gpu_lib, P, B, R, precision):
+    """out[r][band] = sum_p coef[p][r] basis[p][band] against numpy, odd sizes included."""
+    rs = np.random.RandomState(P + B + R)
+    basis = rs.standard_normal((P, B)).astype(precision)
+    coef = rs.standard_normal((P, R)).astype(precision)
+    ctx = _lib.default_context(0)
+    d_b, d_c = ctx.to_device(basis), ctx.to_device(coef)
+    pad = 64
+    d_o = ctx.to_device(np.full(R * B + pad, -3.5, precision))
+    ctx.reconstruct_device(precision, d_b, d_c, d_o, R, P, B)
+    out = ctx.to_host(d_o, (R * B + pad,), precision)
+    for p_ in (d_b, d_c, d_o):
+        ctx.free(p_)
+    assert np.all(out[R * B:] == -3.5)
+    ref = coef.astype(np.float64).T @ basis.astype(np.float64)
+    tol = 1e-13 if precision == np.float64 else 1e-5
+    assert np.max(np.abs(out[:R * B].reshape(R, B) - ref)) / np.max(np.abs(ref)) <= tol
 
 
 # ---------------------------------------------------------------------------------------
