@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--n-test", type=int, default=0, help="rows per GPU per step (0 = workload default)")
     ap.add_argument("--emulators", type=int, default=2101, help="emulators in the c3 batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="timing-only ablation builds (tools/ab_bench.py): do not stop on a parity failure")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
     return ap.parse_args()
 
@@ -262,7 +264,7 @@ def main():
         if der is not None:
             errs.append(gp_oracle.maxnorm_err(ref[2], der))
             names.append("e_deriv")
-    if not max(errs) <= tol:
+    if not max(errs) <= tol and not a.no_parity:
         raise SystemExit("bench parity check failed: %s" % dict(zip(names, errs)))
 
     out = None

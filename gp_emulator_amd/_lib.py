@@ -31,6 +31,7 @@ SIGNATURES = {
     "gp_ctx_create": (c_int, [c_int, PP]),
     "gp_ctx_destroy": (c_int, [c_void_p]),
     "gp_ctx_synchronize": (c_int, [c_void_p]),
+    "gp_ctx_set_debug_buffer": (c_int, [c_void_p, c_void_p]),
     "gp_ctx_device_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_i64),
                                    ctypes.c_char_p, c_int]),
     "gp_predict_wrap_f64": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),

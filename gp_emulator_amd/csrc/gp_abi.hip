@@ -60,6 +60,7 @@ struct gp_ctx {
   // grow-only device scratch for the host-pointer (predict_wrap) path
   void* scratch;
   size_t scratch_bytes;
+  void* dbg;   // diagnostic (GP_STAMPS) builds: device buffer for segment cycle sums
 };
 
 struct gp_model {
@@ -246,6 +247,7 @@ int gp_ctx_create(int device, gp_ctx** out) {
   c->compute_units = prop.multiProcessorCount;
   c->scratch = nullptr;
   c->scratch_bytes = 0;
+  c->dbg = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -262,6 +264,12 @@ int gp_ctx_destroy(gp_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  return GP_OK;
+}
+
+int gp_ctx_set_debug_buffer(gp_ctx* ctx, void* d_buffer) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  ctx->dbg = d_buffer;
   return GP_OK;
 }
 
@@ -422,6 +430,7 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.xa_stride = m->xa_stride;
   a.frags_stride = m->frags_stride;
   a.sd_stride = m->sd_stride;
+  a.dbg = (unsigned long long*)ctx->dbg;
   constexpr int kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
   const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG * m->n_emulators;
   if ((M + kRowsPerWG - 1) / kRowsPerWG > 0x7fffffffLL)

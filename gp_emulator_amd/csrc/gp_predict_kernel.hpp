@@ -41,8 +41,25 @@ namespace gpk {
 #ifndef GP_CHUNK_F32
 #define GP_CHUNK_F32 128   // fp32 MFMAs take half the time: same cover for the LDS-DMA latency
 #endif
-#ifndef GP_PREFETCH
-#define GP_PREFETCH 0   // 1: fetch the next item's test rows during the matrix-core phase (A/B: no gain)
+// Timing-only ablations for tools/ab_bench.py (outputs are wrong when set): GP_ABLATE=1 skips
+// the matrix-core phase, GP_ABLATE=2 replaces phase A's arithmetic by a trivial fill.
+#ifndef GP_ABLATE
+#define GP_ABLATE 0
+#endif
+#ifndef GP_ESTRIN
+#define GP_ESTRIN 0     // 1: Estrin form of the exp polynomial (A/B: slower, more registers)
+#endif
+#ifndef GP_DOTSPLIT
+#define GP_DOTSPLIT 1     // independent partial sums of the exponent's dot product
+#endif
+#ifndef GP_GROUP_F64
+#define GP_GROUP_F64 1
+#endif
+// GP_STAMPS=1: diagnostic build (tools/stamp_profile.py).  Every wave accumulates the shader
+// cycles it spends in six segments of an item and adds them to PredictArgs::dbg at the end.
+// Never used for timing or results (cdna_hip_programming.md section 7, in-kernel stamps).
+#ifndef GP_STAMPS
+#define GP_STAMPS 0
 #endif
 // Predict kernel geometry, per compute type.  fp64: 8 waves = two per SIMD (the register
 // budget of the K_* tile), all in the same phase: fp64 MFMA and fp64 VALU share one pipe on
@@ -81,7 +98,7 @@ template <> struct Real<double> {
   // phase A in expansion form (k = exp(h_i + g + x''.t''), 2 fma per point and dimension):
   // the cancellation costs ~|x''|^2 ulps of 1e-16, far inside the 1e-10 fp64 bar
   static constexpr bool kExpand = true;
-  static constexpr int kGroup = 1;     // training points per software-pipelined group
+  static constexpr int kGroup = GP_GROUP_F64;   // training points per software-pipelined group
   // row (within a 16-block) of C/D register r for lane group g:
   // v_mfma_f64_16x16x4_f64: row = g + 4 r   (cdna_hip_programming.md section 3)
   __host__ __device__ static constexpr int own_sub(int r, int g) { return 4 * r + g; }
@@ -100,6 +117,24 @@ template <> struct Real<double> {
     const double n = __builtin_rint(x * 1.4426950408889634);
     double r = fma(n, -6.93147180559945286e-01, x);
     r = fma(n, -2.31904681384629956e-17, r);
+#if GP_ESTRIN
+    // Estrin evaluation: 13 instructions instead of Horner's 10, but a dependent chain of 5
+    // instead of 10 -- phase A is bound by fp64 dependent-issue latency (~20 cycles per
+    // dependent instruction, one chain per wave), not by instruction count
+    const double r2 = r * r;
+    const double p01 = fma(1.00000000000000666e+00, r, 1.0);
+    const double p23 = fma(1.66666666665544028e-01, r, 5.00000000000000555e-01);
+    const double p45 = fma(8.33333338566834801e-03, r, 4.16666666665732183e-02);
+    const double p67 = fma(1.98411702695461072e-04, r, 1.38888889324666632e-03);
+    const double p89 = fma(2.76401812311866076e-06, r, 2.48015043709117912e-05);
+    const double r4 = r2 * r2;
+    const double q0 = fma(r2, p23, p01);
+    const double q1 = fma(r2, p67, p45);
+    const double q2 = fma(r2, 2.76263485910095559e-07, p89);
+    const double r8 = r4 * r4;
+    const double s0 = fma(r4, q1, q0);
+    const double p = fma(r8, q2, s0);
+#else
     double p = 2.76263485910095559e-07;
     p = fma(p, r, 2.76401812311866076e-06);
     p = fma(p, r, 2.48015043709117912e-05);
@@ -111,6 +146,7 @@ template <> struct Real<double> {
     p = fma(p, r, 5.00000000000000555e-01);
     p = fma(p, r, 1.00000000000000666e+00);
     p = fma(p, r, 1.0);
+#endif
     return ldexp(p, (int)n);
   }
 };
@@ -177,7 +213,23 @@ struct PredictArgs {
   // deriv + e*M*d_actual.  n_emulators = 1 is the plain single-emulator call.
   int n_emulators;
   long long xa_stride, frags_stride, sd_stride;
+  unsigned long long* dbg;   // GP_STAMPS builds only: [8] segment cycle sums; else unused
 };
+
+// Same for N values at once: all exchanges of a step are issued back to back and waited for
+// together (one LDS-crossbar latency per step instead of one per value).
+template <typename T, int N>
+__device__ inline void xor_reduce_groups_n(T* v) {
+  T o[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) o[i] = __shfl_xor(v[i], 16, 64);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += o[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) o[i] = __shfl_xor(v[i], 32, 64);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += o[i];
+}
 
 template <typename T>
 __device__ inline T xor_reduce_groups(T v) {
@@ -232,6 +284,20 @@ __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int 
 // publishes the chunk.
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+#if GP_STAMPS
+#define GP_STAMP(seg)                                                                    \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    unsigned long long now_;                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    seg_sum[seg] += now_ - seg_t0;                                                       \
+    seg_t0 = now_;                                                                       \
+  } while (0)
+#else
+#define GP_STAMP(seg) do { } while (0)
+#endif
+
 template <typename T, int D, int NB>
 __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predict_kernel(PredictArgs<T> p) {
   typedef Real<T> R;
@@ -247,6 +313,11 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
   __shared__ __attribute__((aligned(16))) T s_xa[NP * DS];
   __shared__ __attribute__((aligned(16))) T s_fr[2][kChunk * 64];
   __shared__ T s_sd[2 * D + 1];   // sqrt(e_d), centre c_d, b: broadcast reads, no registers
+  // raw test rows of the wave's tile, double-buffered and private to the wave: the NEXT item's
+  // rows are fetched (coalesced, 8 or 4 B per lane) while the matrix-core phase runs and are
+  // picked up from here at the top of that item -- all waves of a workgroup are in step, so
+  // nothing else would hide the HBM latency of those loads
+  __shared__ T s_rows[2][Geo<T>::kWaves][kTile * D];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -263,18 +334,32 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
   int grp = blockIdx.x;
   while (grp >= n_groups && e < p.n_emulators) { grp -= n_groups; ++e; }
 
-  // Raw test rows of the CURRENT item; the next item's are fetched while the matrix-core
-  // phase runs (all waves of a workgroup are in step, so nothing else would hide the
-  // HBM/L2 latency of these loads at the top of an item).
-  auto load_rows = [&](int grp_, T* dst) {
-    const long long m_ = (long long)grp_ * kRowsPerWG + wave * kTile + ml;
-    const long long mc_ = m_ < p.M ? m_ : p.M - 1;
+  constexpr int NJ = (kTile * D + 63) / 64;        // coalesced loads per lane per tile
+  auto fetch_rows = [&](int grp_, T (&regs)[NJ]) {
+    const long long e0 = ((long long)grp_ * kRowsPerWG + wave * kTile) * p.d_actual;
+    const long long emax = p.M * p.d_actual - 1;
 #pragma unroll
-    for (int d = 0; d < D; ++d) dst[d] = (d < p.d_actual) ? p.testing[mc_ * p.d_actual + d] : T(0);
+    for (int j = 0; j < NJ; ++j) {
+      long long e_ = e0 + lane + 64 * j;
+      e_ = e_ < emax ? e_ : emax;                  // tail tile: stay inside the array
+      regs[j] = p.testing[e_];
+    }
   };
-  T traw[D];
-#if GP_PREFETCH
-  if (e < p.n_emulators) load_rows(grp, traw);
+  auto stash_rows = [&](int buf_, const T (&regs)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (lane + 64 * j < kTile * p.d_actual) s_rows[buf_][wave][lane + 64 * j] = regs[j];
+  };
+  int rbuf = 0;
+  T rregs[NJ];
+  if (e < p.n_emulators) {
+    fetch_rows(grp, rregs);
+    stash_rows(0, rregs);
+  }
+#if GP_STAMPS
+  unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long seg_t0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_t0)::"memory");
 #endif
 
   for (; e < p.n_emulators;) {
@@ -297,27 +382,47 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
     __syncthreads();  // previous item's readers of s_fr[0] are done; new rows visible
     stage_chunk<T>(frags, &s_fr[0][0], wave, lane);
     const T b = s_sd[2 * D];
+    GP_STAMP(0);   // emulator switch, barrier, DMA issue
 
     // ---------------- phase A: K_* tile, mean, gradient --------------------
     // k_i = b exp(-|x''_i - t''|^2 / 2) = exp(h_i + g + x''_i . t''),  g = -|t''|^2 / 2:
     // one fma per (training point, dimension) for the kernel row and one for the gradient
     // sum  G_d = sum_i w_i x''_id,  deriv_d = sqrt(e_d) (G_d - t''_d mu).  Centring on the
     // training mean c keeps |x''|, |t''| (hence the cancellation in h + g + x.t) small.
-#if !GP_PREFETCH
-    load_rows(grp, traw);
-#endif
     T t[D];
     T gm = T(0);
+    {
+      // all LDS reads first, then the arithmetic: one LDS round trip instead of one per
+      // dimension.  Dimensions beyond d_actual have sd = centre = 0 (zero padding) and read a
+      // clamped, valid element, so they come out as exactly 0 without a select.
+      T sdv[D], cv[D], rv[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      t[d] = (d < p.d_actual) ? s_sd[d] * (traw[d] - s_sd[D + d]) : T(0);
-      gm = fma(t[d], t[d], gm);
+      for (int d = 0; d < D; ++d) {
+        const int dc = d < p.d_actual ? d : p.d_actual - 1;
+        sdv[d] = s_sd[d];
+        cv[d] = s_sd[D + d];
+        rv[d] = s_rows[rbuf][wave][ml * p.d_actual + dc];
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        t[d] = sdv[d] * (rv[d] - cv[d]);
+        gm = fma(t[d], t[d], gm);
+      }
     }
     gm *= T(-0.5);
     // 0 for finite test rows, NaN for rows holding a NaN or an infinity: added to every
     // output of the row so that bad inputs surface as NaN despite the clamp inside exp_
     const T poison = gm - gm;
 
+    asm volatile("" :: "v"(gm));
+    // next item (scalar bookkeeping); its test rows are fetched now, in flight during phase A
+    int e_next = e, grp_next = grp + gridDim.x;
+    while (grp_next >= n_groups && e_next < p.n_emulators) { grp_next -= n_groups; ++e_next; }
+    // unconditional (a harmless re-fetch of this item's rows when there is no next item):
+    // no branch, so the fetched values' live range stays simple for the register allocator
+    fetch_rows(e_next < p.n_emulators ? grp_next : grp, rregs);
+
+    GP_STAMP(1);   // test rows loaded and scaled
     T kv[4 * NB];
     T mu = T(0);
     T ga[D];
@@ -348,9 +453,20 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       }
 #pragma unroll
       for (int u = 0; u < GP; ++u) {
+#if GP_ABLATE == 2
+        continue;
+#endif
         if constexpr (R::kExpand) {
+          // GP_DOTSPLIT independent partial sums: shortens the dependent fma chain
+          T part[GP_DOTSPLIT];
+          part[0] = k[u];
 #pragma unroll
-          for (int d = 0; d < D; ++d) k[u] = fma(x[u][d], t[d], k[u]);
+          for (int c = 1; c < GP_DOTSPLIT; ++c) part[c] = T(0);
+#pragma unroll
+          for (int d = 0; d < D; ++d) part[d % GP_DOTSPLIT] = fma(x[u][d], t[d], part[d % GP_DOTSPLIT]);
+#pragma unroll
+          for (int c = 1; c < GP_DOTSPLIT; ++c) part[0] += part[c];
+          k[u] = part[0];
         } else {
           T r2 = T(0);
 #pragma unroll
@@ -364,7 +480,11 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       // stage 2: kernel values
 #pragma unroll
       for (int u = 0; u < GP; ++u) {
+#if GP_ABLATE == 2
+        k[u] = x[u][0] + t[0];
+#else
         k[u] = R::kExpand ? R::exp_(k[u]) : b * R::exp_(k[u]);
+#endif
         kv[q0 + u] = k[u];
       }
       // stage 3: mean and gradient sums
@@ -372,15 +492,29 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       for (int u = 0; u < GP; ++u) {
         const T w = k[u] * al[u];
         mu += w;
+#if GP_ABLATE == 2
+        ga[u % D] += w;
+#else
 #pragma unroll
         for (int d = 0; d < D; ++d) ga[d] = fma(w, x[u][d], ga[d]);
+#endif
       }
     });
+    GP_STAMP(2);   // phase A proper
+    // (batches of 6: a whole-array batch raises the live-register peak enough to spill)
     mu = xor_reduce_groups(mu) + poison;
+    static_for<(D + 5) / 6>([&](auto bc) {
+      constexpr int d0 = decltype(bc)::value * 6;
+      constexpr int nb_ = (D - d0 < 6) ? (D - d0) : 6;
+      xor_reduce_groups_n<T, nb_>(&ga[d0]);
+    });
+    {
+      T sdv[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const T gsum = xor_reduce_groups(ga[d]);
-      ga[d] = s_sd[d] * (R::kExpand ? fma(-t[d], mu, gsum) : gsum);
+      for (int d = 0; d < D; ++d) sdv[d] = s_sd[d];
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+        ga[d] = sdv[d] * (R::kExpand ? fma(-t[d], mu, ga[d]) : ga[d]);
     }
 
     if (m < p.M) {
@@ -394,17 +528,18 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       }
     }
 
-    // next item (scalar bookkeeping) and its test rows, in flight during phase B
-    int e_next = e, grp_next = grp + gridDim.x;
-    while (grp_next >= n_groups && e_next < p.n_emulators) { grp_next -= n_groups; ++e_next; }
-#if GP_PREFETCH
-    if (e_next < p.n_emulators) load_rows(grp_next, traw);
-#endif
+    GP_STAMP(3);   // lane-group reductions, mean / gradient stores
+    stash_rows(rbuf ^ 1, rregs);   // next item's rows (fetched during phase A) -> LDS
 
     // ---------------- phase B: variance on the matrix core -----------------
     T vacc = T(0);
     acc_t acc;
+#if GP_ABLATE == 1
+    static_for<4 * NB>([&](auto qc) { vacc += kv[decltype(qc)::value]; });
+    static_for<0>([&](auto fc) {
+#else
     static_for<NF>([&](auto fc) {
+#endif
       constexpr int f = decltype(fc)::value;
       constexpr int c = f / kChunk, fl = f % kChunk;
       constexpr int pair = f >> 2, s = f & 3;
@@ -423,12 +558,21 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
         for (int r = 0; r < 4; ++r) vacc = fma(acc[r], kv[4 * J + r], vacc);
       }
     });
+    rbuf ^= 1;
+    GP_STAMP(4);   // phase B
     vacc = xor_reduce_groups(vacc);
     if (m < p.M && g == 1) o_var[m] = b - vacc + poison;
 
     e = e_next;
     grp = grp_next;
+    GP_STAMP(5);   // variance reduction and store
   }
+#if GP_STAMPS
+  if (lane == 0 && p.dbg) {
+    for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&p.dbg[k_], seg_sum[k_]);
+    atomicAdd(&p.dbg[7], 1ull);   // wave count
+  }
+#endif
 }
 
 }  // namespace gpk

@@ -58,6 +58,9 @@ int gp_device_count(int* count);
 int gp_ctx_create(int device, gp_ctx** out);
 int gp_ctx_destroy(gp_ctx* ctx);
 int gp_ctx_synchronize(gp_ctx* ctx);
+/* Diagnostic builds only (-DGP_STAMPS=1, tools/stamp_profile.py): device buffer of 8 uint64
+ * that the predict kernel adds its per-segment cycle sums to.  Ignored by normal builds. */
+int gp_ctx_set_debug_buffer(gp_ctx* ctx, void* d_buffer);
 /* number of compute units and HBM bytes of the context's device */
 int gp_ctx_device_info(gp_ctx* ctx, int* compute_units, int64_t* hbm_bytes, char* name, int name_len);
 
