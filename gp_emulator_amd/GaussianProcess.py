@@ -118,8 +118,14 @@ class GaussianProcess:
         theta_size = self.theta.size
         assert n_inputs == self.D
 
+        # float32 predict on float64 data through the row-major boundary: the library converts
+        # while it stages, nothing is cast on the host
+        mixed = (self.row_major_boundary and precision == np.float32
+                 and np.asarray(testing).dtype == np.float64)
+        host_dt = np.dtype(np.float64) if mixed else precision
+
         def cast(a, size):   # 1-D, contiguous, ``precision`` (reference :289-292)
-            return np.ascontiguousarray(np.asarray(a).reshape(size), dtype=precision)
+            return np.ascontiguousarray(np.asarray(a).reshape(size), dtype=host_dt)
         inputs = cast(self.inputs, n_train * n_inputs)
         invQt = cast(self.invQt, n_train)
         invQ = cast(self.invQ, n_train * n_train)
@@ -129,13 +135,14 @@ class GaussianProcess:
         error = np.empty(n_predict)
         deriv = np.empty((n_predict, n_inputs))
         ind_start, ind_end = self.get_gpu_block(n_predict, threshold)
-        direct = self.row_major_boundary and precision == np.float64
+        direct = self.row_major_boundary and host_dt == np.float64
+        rows_fn = _gpu_predict.predict_rows_f32_h64 if mixed else _gpu_predict.predict_rows
         for block_start, block_end in zip(ind_start, ind_end):
             n_blk = int(block_end - block_start)
             testing_block = cast(testing[block_start:block_end, :], n_blk * n_inputs)
             if direct:
                 # float64: the library writes into the final arrays' own slices
-                _gpu_predict.predict_rows(expX, inputs, invQt, invQ, testing_block,
+                rows_fn(expX, inputs, invQt, invQ, testing_block,
                                           result[block_start:block_end],
                                           error[block_start:block_end],
                                           deriv[block_start:block_end, :].reshape(-1),

@@ -40,6 +40,15 @@ def predict_rows(expX, inputs, invQt, invQ, testing, result, error, deriv,
                  n_predict, n_train, n_inputs, theta_size)
 
 
+def predict_rows_f32_h64(expX, inputs, invQt, invQ, testing, result, error, deriv,
+                         n_predict, n_train, n_inputs, theta_size):
+    """``predict_rows`` for float64 arrays with float32 arithmetic on the device: the library
+    converts while it stages, so ``gpu_predict(precision=np.float32)`` needs no float32 copies
+    of its (float64) inputs and outputs.  Not part of the reference module."""
+    return _call("rows_f32_h64", expX, inputs, invQt, invQ, testing, result, error, deriv,
+                 n_predict, n_train, n_inputs, theta_size)
+
+
 def _call(kind, expX, inputs, invQt, invQ, testing, result, error, deriv,
           n_predict, n_train, n_inputs, theta_size):
     arrays = (expX, inputs, invQt, invQ, testing, result, error, deriv)
@@ -69,7 +78,12 @@ def _call(kind, expX, inputs, invQt, invQ, testing, result, error, deriv,
         if not dict(zip(_NAMES, arrays))[name].flags["WRITEABLE"]:
             raise ValueError("%s must be writeable" % name)
     ctx = _lib.default_context(0)
-    name = "gp_predict_%s_%s" % (kind, "f64" if dt == np.float64 else "f32")
+    if kind == "rows_f32_h64":
+        if dt != np.float64:
+            raise TypeError("predict_rows_f32_h64 takes float64 arrays")
+        name = "gp_predict_rows_f32_h64"
+    else:
+        name = "gp_predict_%s_%s" % (kind, "f64" if dt == np.float64 else "f32")
     fn = getattr(ctx.lib, name)
     p = [a.ctypes.data_as(_lib.c_void_p) for a in arrays]
     _lib.check(fn(ctx.h, *p, n_predict, n_train, n_inputs, theta_size), "gp_predict_wrap")

@@ -38,6 +38,7 @@ SIGNATURES = {
     "gp_predict_wrap_f32": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
     "gp_predict_rows_f64": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
     "gp_predict_rows_f32": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
+    "gp_predict_rows_f32_h64": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
     "gp_model_create_f64": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_model_create_f32": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_batch_create_f64": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "gp_dispatch.hpp"
@@ -61,6 +62,13 @@ struct gp_ctx {
   void* scratch;
   size_t scratch_bytes;
   void* dbg;   // diagnostic (GP_STAMPS) builds: device buffer for segment cycle sums
+  // pipelined host-pointer path: second stream, pinned staging (2 slots), slot events
+  hipStream_t stream2;
+  void* stage_in[2];
+  void* stage_out[2];
+  size_t stage_in_bytes, stage_out_bytes;
+  hipEvent_t slot_done[2];
+  bool pipe_ready;
 };
 
 struct gp_model {
@@ -118,8 +126,8 @@ static inline int row_stride_of(int kd) { return gpk::row_stride(kd); }
 // ------------------------------------------------------------------------------------
 // host-side packing (double arithmetic, one rounding to T at the end)
 // ------------------------------------------------------------------------------------
-template <typename T>
-static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* invQ, int N,
+template <typename T, typename TH = T>
+static int pack_model(const TH* expX, const TH* inputs, const TH* invQt, const TH* invQ, int N,
                       int D, int theta_size, T* xa, T* frags, T* sd, T* b) {
   if (!expX || !inputs || !invQt || !xa || !sd || !b || (invQ && !frags))
     return fail(GP_ERR_INVALID, "null pointer");
@@ -147,8 +155,8 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
     sd[d] = (T)sdd[d];
     sd[kd + d] = (T)ctr[d];
   }
-  *b = expX[D];
-  sd[2 * kd] = expX[D];
+  *b = (T)expX[D];
+  sd[2 * kd] = (T)expX[D];
   const double lnb = std::log((double)expX[D]);
   std::memset(xa, 0, sizeof(T) * (size_t)NP * DS);
   for (int i = 0; i < N; ++i) {
@@ -159,7 +167,7 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
       xa[(size_t)i * DS + d] = xr;
       n2 += (double)xr * (double)xr;
     }
-    xa[(size_t)i * DS + kd] = invQt[i];
+    xa[(size_t)i * DS + kd] = (T)invQt[i];
     xa[(size_t)i * DS + kd + 1] = (T)(lnb - 0.5 * n2);
   }
   // S' in fragment order: fragment (I <= J, s), lane l holds
@@ -168,7 +176,7 @@ static int pack_model(const T* expX, const T* inputs, const T* invQt, const T* i
   //   k^T M k = sum_J sum_{I<=J} k_I^T S'_IJ k_J        for ANY matrix M.
   if (!invQ) return GP_OK;   // Hessian-only model: no variance operand
   if (knb == 0) {            // general-shape kernel: invQ as given
-    for (size_t q = 0; q < (size_t)N * N; ++q) frags[q] = invQ[q];
+    for (size_t q = 0; q < (size_t)N * N; ++q) frags[q] = (T)invQ[q];
     return GP_OK;
   }
   const int nfp = gpk::frag_count_padded(knb, gpk::Geo<T>::kChunk);
@@ -248,6 +256,10 @@ int gp_ctx_create(int device, gp_ctx** out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->dbg = nullptr;
+  c->stream2 = nullptr;
+  c->stage_in[0] = c->stage_in[1] = c->stage_out[0] = c->stage_out[1] = nullptr;
+  c->stage_in_bytes = c->stage_out_bytes = 0;
+  c->pipe_ready = false;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -262,6 +274,12 @@ int gp_ctx_destroy(gp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->stage_in[k]) (void)hipHostFree(ctx->stage_in[k]);
+    if (ctx->stage_out[k]) (void)hipHostFree(ctx->stage_out[k]);
+    if (ctx->pipe_ready) (void)hipEventDestroy(ctx->slot_done[k]);
+  }
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return GP_OK;
@@ -322,9 +340,9 @@ int gp_pack_model_f32(const float* expX, const float* inputs, const float* invQt
 
 // Pack and upload E emulators that share the training inputs (E = 1: the plain case).
 // expX is [E][theta_size], invQt [E][N], invQ [E][N][N] (or null: Hessian-only model).
-template <typename T>
-static int model_create(gp_ctx* ctx, int E, const T* expX, const T* inputs, const T* invQt,
-                        const T* invQ, int N, int D, int theta_size, gp_model** out) {
+template <typename T, typename TH = T>
+static int model_create(gp_ctx* ctx, int E, const TH* expX, const TH* inputs, const TH* invQt,
+                        const TH* invQ, int N, int D, int theta_size, gp_model** out) {
   if (!ctx || !out) return fail(GP_ERR_INVALID, "null context or output");
   *out = nullptr;
   if (E <= 0) return fail(GP_ERR_INVALID, "n_emulators must be positive");
@@ -355,7 +373,7 @@ static int model_create(gp_ctx* ctx, int E, const T* expX, const T* inputs, cons
   std::vector<T> xa(xa_len), fr(fr_len), sd(sd_len);
   for (int k = 0; k < E && e == hipSuccess && rc == GP_OK; ++k) {
     T b;
-    rc = pack_model<T>(expX + (size_t)k * theta_size, inputs, invQt + (size_t)k * N,
+    rc = pack_model<T, TH>(expX + (size_t)k * theta_size, inputs, invQt + (size_t)k * N,
                        invQ ? invQ + (size_t)k * N * N : nullptr, N, D, theta_size,
                        xa.data(), invQ ? fr.data() : nullptr, sd.data(), &b);
     if (rc) break;
@@ -388,7 +406,9 @@ hipError_t launch_generic<double>(const gpk::GenericArgs<double>& a, int grid, h
 
 template <typename T>
 static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_mu,
-                          void* d_var, void* d_deriv, int64_t M, int layout) {
+                          void* d_var, void* d_deriv, int64_t M, int layout,
+                          hipStream_t stream = nullptr) {
+  if (!stream) stream = ctx->stream;
   if (m->kernel_nb == 0) {   // general-shape kernel
     if (m->n_emulators != 1)
       return fail(GP_ERR_UNSUPPORTED, "batched emulators need n_train <= %d and n_inputs <= %d",
@@ -411,7 +431,7 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
     int64_t tiles = (M + 15) / 16;
     int64_t grid = (int64_t)ctx->compute_units * 4;
     if (grid > tiles) grid = tiles;
-    hipError_t e = launch_generic<T>(g, (int)grid, ctx->stream);
+    hipError_t e = launch_generic<T>(g, (int)grid, stream);
     if (e != hipSuccess) return fail(GP_ERR_HIP, "generic kernel launch: %s", hipGetErrorString(e));
     return GP_OK;
   }
@@ -438,7 +458,7 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   // persistent grid: the kernel's occupancy (2 waves per SIMD), grid-stride over work items
   int64_t grid = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU;
   if (grid > groups) grid = groups;
-  hipError_t e = launch<T>(m->kernel_nb, m->kernel_d, a, (int)grid, ctx->stream);
+  hipError_t e = launch<T>(m->kernel_nb, m->kernel_d, a, (int)grid, stream);
   if (e != hipSuccess) return fail(GP_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return GP_OK;
 }
@@ -489,19 +509,163 @@ static int ensure_scratch(gp_ctx* ctx, size_t bytes) {
   return GP_OK;
 }
 
+// ---- pipelined host-pointer path --------------------------------------------------------
+// Large calls are cut into slabs that flow through two slots: while the GPU works on slab s
+// (H2D, kernel, D2H on the slot's own stream, all from/to PINNED staging), the calling thread
+// and a few helpers copy slab s+1 in and slab s-1 out of the caller's pageable arrays
+// (converting between the caller's type TH and the compute type T on the way, so a float32
+// predict on float64 numpy arrays needs no numpy casts at all).
+static int host_threads() {
+  static int n = [] {
+    const char* ev = getenv("GP_HOST_THREADS");
+    int v = ev ? atoi(ev) : 4;
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  return n;
+}
+
+template <typename F>
+static void parallel_ranges(size_t n, F f) {
+  const int nt = host_threads();
+  if (nt <= 1 || n < (size_t)1 << 16) { f((size_t)0, n); return; }
+  const size_t per = (n + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) {
+    const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+    if (lo < hi) th.emplace_back([=] { f(lo, hi); });
+  }
+  f((size_t)0, per < n ? per : n);
+  for (auto& x : th) x.join();
+}
+
+template <typename TD, typename TS>
+static inline void convert_range(TD* dst, const TS* src, size_t lo, size_t hi) {
+  if (sizeof(TD) == sizeof(TS)) std::memcpy((void*)(dst + lo), (const void*)(src + lo), (hi - lo) * sizeof(TD));
+  else for (size_t i = lo; i < hi; ++i) dst[i] = (TD)src[i];
+}
+template <typename TD, typename TS>
+static void convert_copy(TD* dst, const TS* src, size_t n) {
+  parallel_ranges(n, [=](size_t lo, size_t hi) { convert_range(dst, src, lo, hi); });
+}
+
+static int ensure_pipeline(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
+  if (!ctx->pipe_ready) {
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->slot_done[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->slot_done[1], hipEventDisableTiming));
+    ctx->pipe_ready = true;
+  }
+  if (ctx->stage_in_bytes < in_bytes) {
+    for (int k = 0; k < 2; ++k) {
+      if (ctx->stage_in[k]) HIP_TRY(hipHostFree(ctx->stage_in[k]));
+      ctx->stage_in[k] = nullptr;
+      HIP_TRY(hipHostMalloc(&ctx->stage_in[k], in_bytes, hipHostMallocDefault));
+    }
+    ctx->stage_in_bytes = in_bytes;
+  }
+  if (ctx->stage_out_bytes < out_bytes) {
+    for (int k = 0; k < 2; ++k) {
+      if (ctx->stage_out[k]) HIP_TRY(hipHostFree(ctx->stage_out[k]));
+      ctx->stage_out[k] = nullptr;
+      HIP_TRY(hipHostMalloc(&ctx->stage_out[k], out_bytes, hipHostMallocDefault));
+    }
+    ctx->stage_out_bytes = out_bytes;
+  }
+  return GP_OK;
+}
+
+constexpr int64_t kPipeSlab = 262144;      // rows per slab of the pipelined path
+constexpr int64_t kPipeMinRows = 65536;    // below this the simple path is as fast
+
+// T = compute type, TH = the caller's host type (T, or double with T = float)
+template <typename T, typename TH>
+static int predict_host_pipelined(gp_ctx* ctx, const gp_model* m, const TH* testing, TH* result,
+                                  TH* error, TH* deriv, int64_t M, int D, int layout) {
+  const int64_t slab = kPipeSlab;
+  const size_t in_elems = (size_t)slab * D, out_elems = (size_t)slab * (2 + D);
+  int rc = ensure_pipeline(ctx, in_elems * sizeof(T), out_elems * sizeof(T));
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, 2 * (in_elems + out_elems) * sizeof(T));
+  if (rc) return rc;
+  hipStream_t streams[2] = {ctx->stream, ctx->stream2};
+  const int64_t ns = (M + slab - 1) / slab;
+  hipError_t e = hipSuccess;
+  auto rows_of = [&](int64_t s) { return (s + 1) * slab <= M ? slab : M - s * slab; };
+  auto copy_out = [&](int64_t s) -> hipError_t {       // pinned slot -> caller's arrays
+    const int k = (int)(s & 1);
+    const int64_t n = rows_of(s), s0 = s * slab;
+    hipError_t ee = hipEventSynchronize(ctx->slot_done[k]);
+    if (ee != hipSuccess) return ee;
+    const T* o = (const T*)ctx->stage_out[k];
+    // one parallel region per slab: every helper takes a range of ROWS and copies its part of
+    // all three outputs (threads are spawned per region, so regions are kept few and large)
+    parallel_ranges((size_t)n, [=](size_t lo, size_t hi) {
+      convert_range(result + s0, o, lo, hi);
+      convert_range(error + s0, o + n, lo, hi);
+      if (layout == GP_DERIV_ROWMAJOR) {
+        convert_range(deriv + (size_t)s0 * D, o + 2 * n, lo * D, hi * D);
+      } else {
+        for (int d = 0; d < D; ++d) convert_range(deriv + (size_t)d * M + s0, o + 2 * n + (size_t)d * n, lo, hi);
+      }
+    });
+    return hipSuccess;
+  };
+  for (int64_t s = 0; s < ns && e == hipSuccess; ++s) {
+    const int k = (int)(s & 1);
+    const int64_t n = rows_of(s), s0 = s * slab;
+    if (s >= 2) e = copy_out(s - 2);                   // frees slot k (its D2H has finished)
+    if (e != hipSuccess) break;
+    convert_copy((T*)ctx->stage_in[k], testing + (size_t)s0 * D, (size_t)n * D);
+    T* d_in = (T*)ctx->scratch + (size_t)k * (in_elems + out_elems);
+    T* d_out = d_in + in_elems;
+    e = hipMemcpyAsync(d_in, ctx->stage_in[k], sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, streams[k]);
+    if (e != hipSuccess) break;
+    rc = predict_device<T>(ctx, m, d_in, d_out, d_out + n, d_out + 2 * n, n, layout, streams[k]);
+    if (rc) break;
+    e = hipMemcpyAsync(ctx->stage_out[k], d_out, sizeof(T) * (size_t)n * (2 + D), hipMemcpyDeviceToHost, streams[k]);
+    if (e == hipSuccess) e = hipEventRecord(ctx->slot_done[k], streams[k]);
+  }
+  for (int64_t s = (ns >= 2 ? ns - 2 : 0); s < ns && e == hipSuccess && rc == GP_OK; ++s) e = copy_out(s);
+  // leave both streams idle whatever happened (staging buffers are reused by the next call)
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "pipelined predict: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
 // Host-pointer path = predict_wrap: upload constants + test rows, one launch, download.
 // Rows are processed in slabs so the device scratch stays bounded for any n_predict.
 template <typename T>
-static int predict_wrap(gp_ctx* ctx, const T* expX, const T* inputs, const T* invQt,
-                        const T* invQ, const T* testing, T* result, T* error, T* deriv,
+static int predict_wrap_simple(gp_ctx* ctx, gp_model* m, const T* testing, T* result, T* error,
+                               T* deriv, int64_t M, int D, int layout);
+
+template <typename T, typename TH = T>
+static int predict_wrap(gp_ctx* ctx, const TH* expX, const TH* inputs, const TH* invQt,
+                        const TH* invQ, const TH* testing, TH* result, TH* error, TH* deriv,
                         int64_t M, int N, int D, int theta_size, int layout = GP_DERIV_DMAJOR) {
   if (!ctx) return fail(GP_ERR_INVALID, "null context");
   if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
   if (M > 0 && (!testing || !result || !error || !deriv)) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
   gp_model* m = nullptr;
-  int rc = model_create<T>(ctx, 1, expX, inputs, invQt, invQ, N, D, theta_size, &m);
+  int rc = model_create<T, TH>(ctx, 1, expX, inputs, invQt, invQ, N, D, theta_size, &m);
   if (rc) return rc;
   if (M == 0) { gp_model_destroy(m); return GP_OK; }
+  if (M >= kPipeMinRows || sizeof(T) != sizeof(TH)) {
+    rc = predict_host_pipelined<T, TH>(ctx, m, testing, result, error, deriv, M, D, layout);
+    gp_model_destroy(m);
+    return rc;
+  }
+  return predict_wrap_simple<T>(ctx, m, (const T*)(const void*)testing, (T*)(void*)result,
+                                (T*)(void*)error, (T*)(void*)deriv, M, D, layout);
+}
+
+// Small calls: pageable copies straight from/to the caller's arrays (T == TH here).
+template <typename T>
+static int predict_wrap_simple(gp_ctx* ctx, gp_model* m, const T* testing, T* result, T* error,
+                               T* deriv, int64_t M, int D, int layout) {
+  int rc = GP_OK;
   const int64_t slab = M < (int64_t)(1 << 22) ? M : (int64_t)(1 << 22);  // rows per slab
   const size_t per_row = sizeof(T) * (size_t)(2 * D + 2);
   rc = ensure_scratch(ctx, per_row * (size_t)slab);
@@ -672,6 +836,12 @@ int gp_predict_rows_f64(gp_ctx* ctx, const double* expX, const double* inputs, c
                         double* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
   return predict_wrap<double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
                               n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
+}
+int gp_predict_rows_f32_h64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
+                            const double* invQ, const double* testing, double* result, double* error,
+                            double* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
+  return predict_wrap<float, double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                                     n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
 }
 int gp_predict_rows_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
                         const float* invQ, const float* testing, float* result, float* error,

@@ -101,6 +101,15 @@ int gp_predict_rows_f32(gp_ctx* ctx, const float* expX, const float* inputs,
                         float* result, float* error, float* deriv,
                         int64_t n_predict, int n_train, int n_inputs, int theta_size);
 
+/* The same with float64 host arrays but FLOAT32 arithmetic on the device (what
+ * gp.predict(is_gpu=True, precision=np.float32) means when the caller's arrays are float64):
+ * constants are packed from the float64 values, test rows / outputs are converted while they
+ * are staged, so the caller needs no float32 copies of anything. */
+int gp_predict_rows_f32_h64(gp_ctx* ctx, const double* expX, const double* inputs,
+                            const double* invQt, const double* invQ, const double* testing,
+                            double* result, double* error, double* deriv,
+                            int64_t n_predict, int n_train, int n_inputs, int theta_size);
+
 /* ---- device-resident form --------------------------------------------------------------
  * gp_model_create_*: pack (host side, in double) and upload the per-emulator constants the
  * reference re-uploads for every block (predict.cu:17-33): sqrt(e)-scaled training inputs

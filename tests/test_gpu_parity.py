@@ -91,7 +91,10 @@ def test_gaussianprocess_predict_flow(gpu_lib, precision):
     gp.row_major_boundary = False
     got2 = gp.predict(testing, is_gpu=True, precision=precision, threshold=1e4)
     for x, y in zip(got, got2):
-        assert np.array_equal(x, y)
+        if precision == np.float64:
+            assert np.array_equal(x, y)
+        else:   # row-major boundary packs the constants from float64, predict_wrap from float32
+            assert np.max(np.abs(x - y)) / np.max(np.abs(x)) <= 1e-5
 
 
 @pytest.mark.parametrize("M", [1, 15, 16, 17, 63, 64, 65, 127, 129, 1000])
