@@ -413,3 +413,29 @@ def test_every_kernel_size_class(gpu_lib, N, D):
     gp = make_gp(g)
     h = gp.hessian(testing[:40], is_gpu=True)
     assert gp_oracle.maxnorm_err(gp_oracle.hessian(inputs, theta, invQt, testing[:40]), h) <= 1e-10
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_pipelined_host_path(gpu_lib, precision):
+    """Calls of >= 65536 rows go through the library's slab pipeline (pinned staging, two
+    slots, threaded copy/convert): several slabs with a ragged last one, through
+    predict (row-major boundary, float32-on-float64 conversion for fp32), predict_wrap
+    (dimension-major, strided copy-out) and with several row blocks."""
+    N, D, M = 250, 10, 2 * 262144 + 777
+    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(31, N, D, M)
+    g = dict(inputs=inputs, theta=theta, invQ=invQ, invQt=invQt, testing=testing)
+    gp = make_gp(g)
+    idx = np.concatenate([np.arange(0, 300), np.arange(262144 - 150, 262144 + 150),
+                          np.arange(M - 300, M)])
+    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[idx])
+    got = gp.predict(testing, is_gpu=True, precision=precision, threshold=1e7)
+    assert max(errs(ref, [x[idx] for x in got])) <= TOL[precision]
+    got_b = gp.predict(testing, is_gpu=True, precision=precision, threshold=2e5)
+    if precision == np.float64:
+        for x, y in zip(got, got_b):
+            assert np.array_equal(x, y)          # block boundaries change nothing
+    wrapped = wrap(g, precision)                  # predict_wrap: dimension-major deriv
+    assert max(errs(ref, [x[idx] for x in wrapped])) <= TOL[precision]
+    if precision == np.float64:
+        for x, y in zip(got, wrapped):
+            assert np.array_equal(x, y)
