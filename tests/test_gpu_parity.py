@@ -439,3 +439,23 @@ def test_pipelined_host_path(gpu_lib, precision):
     if precision == np.float64:
         for x, y in zip(got, wrapped):
             assert np.array_equal(x, y)
+
+
+def test_real_emulator_variance_against_extended_precision(gpu_lib):
+    """On the real (cond ~1e7) emulator var = b - k^T invQ k cancels ~1e7-fold, so 'parity with
+    numpy' is parity with numpy's own rounding noise.  Evaluate the same formula in 80-bit
+    extended precision (numpy longdouble, from the float64 kernel row of the oracle) and require
+    the GPU's error against that truth to be of the size of the numpy path's own error."""
+    g = load_golden("prosail_pc0")
+    D = g["inputs"].shape[1]
+    b = float(np.exp(g["theta"][D]))
+    t = g["testing"][:200]
+    k = gp_oracle.kernel_rows(g["inputs"], g["theta"], t).astype(np.longdouble)      # (N, M)
+    Q = g["invQ"].astype(np.longdouble)
+    truth = np.longdouble(b) - np.einsum("im,ij,jm->m", k, Q, k)
+    mu, var, der = wrap(g, np.float64, t)
+    e_gpu = float(np.max(np.abs(var.astype(np.longdouble) - truth))) / b
+    e_np = float(np.max(np.abs(g["var"][:200].astype(np.longdouble) - truth))) / b
+    print("variance vs 80-bit truth, relative to b: gpu %.3g, numpy path %.3g" % (e_gpu, e_np))
+    assert e_gpu <= 1e-8
+    assert e_gpu <= 5 * e_np + 1e-12

@@ -8,11 +8,14 @@ from gp_emulator_amd import _lib
 from oracle import gp_oracle
 
 ctx = _lib.Context(0)
+DT = np.float32 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else np.float64
+ISZ = np.dtype(DT).itemsize
+WAVES = 12 if DT == np.float32 else 8
 M = 1000000
 inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1, 250, 11, M)
-model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, np.float64)
-d_t = ctx.to_device(testing)
-d_mu, d_var, d_der = ctx.malloc(M * 8), ctx.malloc(M * 8), ctx.malloc(M * 88)
+model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, DT)
+d_t = ctx.to_device(testing.astype(DT))
+d_mu, d_var, d_der = ctx.malloc(M * ISZ), ctx.malloc(M * ISZ), ctx.malloc(M * 11 * ISZ)
 d_dbg = ctx.to_device(np.zeros(8, np.uint64))
 _lib.check(ctx.lib.gp_ctx_set_debug_buffer(ctx.h, d_dbg))
 for _ in range(2):
@@ -28,7 +31,7 @@ waves = s[7] / K
 names = ["0 emulator switch + barrier + DMA issue", "1 test rows load + scale", "2 phase A (kernel row, mean, grad sums)",
          "3 lane-group reductions + mu/deriv stores", "4 phase B (MFMA variance)", "5 var reduction + store"]
 tot = s[:6].sum()
-items_per_wave = (M / 128) / (waves / 8)
+items_per_wave = (M / (16 * WAVES)) / (waves / WAVES)
 print("waves per launch %.0f, items per wave %.2f" % (waves, items_per_wave))
 for n, v in zip(names, s[:6]):
     print("%-46s %5.1f %%   %8.0f cycles per item" % (n, 100 * v / tot, v / K / waves / items_per_wave))
