@@ -459,3 +459,31 @@ def test_real_emulator_variance_against_extended_precision(gpu_lib):
     print("variance vs 80-bit truth, relative to b: gpu %.3g, numpy path %.3g" % (e_gpu, e_np))
     assert e_gpu <= 1e-8
     assert e_gpu <= 5 * e_np + 1e-12
+
+
+def test_bench_json_contract(gpu_lib):
+    """bench.py prints ONE JSON line with the driver's keys plus roofline and cpu_baseline."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1",
+                        "--cpu-sample", "20000"], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["dtype"] == "f64" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["value"] > 1e8          # a silent CPU fallback would be ~1e5
+    assert max(d["parity"]["e_mu"], d["parity"]["e_var"], d["parity"]["e_deriv"]) <= 1e-10
