@@ -487,3 +487,16 @@ def test_bench_json_contract(gpu_lib):
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] > 1e8          # a silent CPU fallback would be ~1e5
     assert max(d["parity"]["e_mu"], d["parity"]["e_var"], d["parity"]["e_deriv"]) <= 1e-10
+
+
+def test_predict_sharded_threads_on_gpu(gpu_lib):
+    """multi_gpu.predict_sharded with the real HIP path: one thread + one context per shard
+    (here three shards on the one GPU of the test box), host gather into disjoint slices."""
+    from gp_emulator_amd import multi_gpu
+    g = synthetic_case("c4_n300_d11")
+    gp = make_gp(g)
+    mu, var, der = multi_gpu.predict_sharded(gp, g["testing"], devices=[0, 0, 0])
+    assert max(errs((g["mu"], g["var"], g["deriv"]), (mu, var, der))) <= 1e-10
+    one = gp.gpu_model(np.float64).predict(g["testing"])
+    for a, b in zip(one, (mu, var, der)):
+        assert np.array_equal(a, b)
