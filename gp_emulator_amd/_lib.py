@@ -52,6 +52,7 @@ SIGNATURES = {
     "gp_hessian_f64": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_hessian_f32": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_reconstruct_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int]),
+    "gp_frag_index": (c_int, [c_int, c_int, c_int, c_int]),
     "gp_pack_sizes": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                               ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "gp_pack_model_f64": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),

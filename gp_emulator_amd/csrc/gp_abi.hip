@@ -184,7 +184,7 @@ static int pack_model(const TH* expX, const TH* inputs, const TH* invQt, const T
   for (int J = 0; J < knb; ++J)
     for (int I = 0; I <= J; ++I)
       for (int s = 0; s < 4; ++s) {
-        T* f = frags + (size_t)gpk::frag_index(I, J, s) * 64;
+        T* f = frags + (size_t)gpk::frag_index(I, J, s, knb) * 64;
         for (int l = 0; l < 64; ++l) {
           const int i = gpk::own_index<T>(I, s, l >> 4);
           const int j = 16 * J + (l & 15);
@@ -308,6 +308,11 @@ int gp_ctx_device_info(gp_ctx* ctx, int* compute_units, int64_t* hbm_bytes, char
     snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
   }
   return GP_OK;
+}
+
+int gp_frag_index(int kernel_nb, int I, int J, int s) {
+  if (kernel_nb <= 0 || I < 0 || J < I || J >= kernel_nb || s < 0 || s > 3) return -1;
+  return gpk::frag_index(I, J, s, kernel_nb);
 }
 
 int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,

@@ -174,16 +174,50 @@ __host__ __device__ constexpr int own_index(int I, int s, int g) {
   return 16 * I + Real<T>::own_sub(s, g);
 }
 
-// Position of fragment (I <= J, s) in consumption order.
-__host__ __device__ constexpr int frag_index(int I, int J, int s) {
-  return (J * (J + 1) / 2 + I) * 4 + s;
-}
+// Fragment order.  GP_PAIRED = 0: column block by column block, (J, I <= J, s).
+// GP_PAIRED = 1: column blocks in pairs (J0, J0 + 1) whose k-steps alternate, so that two
+// independent accumulator chains are in flight per wave (a single dependent fp64 MFMA chain
+// reaches 82 % of the matrix pipe from one wave per SIMD, two chains 93 % --
+// tools/mfma_f64_probe.hip).
+#ifndef GP_PAIRED
+#define GP_PAIRED 0
+#endif
+struct FragId { int I, J, s; };
 __host__ __device__ constexpr int frag_count(int NB) { return NB * (NB + 1) / 2 * 4; }
-// Inverse of frag_index on the pair index: column block J of pair (I <= J).
-__host__ __device__ constexpr int pair_col(int pair) {
+// n-th fragment in consumption order (by simulation; evaluated at compile time in the kernel)
+__host__ __device__ constexpr FragId frag_at(int n, int NB) {
+#if GP_PAIRED
+  int cnt = 0;
+  for (int J0 = 0; J0 < NB; J0 += 2) {
+    const int J1 = J0 + 1 < NB ? J0 + 1 : -1;
+    const int Imax = J1 >= 0 ? J1 : J0;
+    for (int I = 0; I <= Imax; ++I)
+      for (int s = 0; s < 4; ++s) {
+        if (I <= J0) { if (cnt == n) return FragId{I, J0, s}; ++cnt; }
+        if (J1 >= 0) { if (cnt == n) return FragId{I, J1, s}; ++cnt; }
+      }
+  }
+  return FragId{0, 0, 0};
+#else
+  const int pair = n >> 2;
   int J = 0;
   while ((J + 1) * (J + 2) / 2 <= pair) ++J;
-  return J;
+  (void)NB;
+  return FragId{pair - J * (J + 1) / 2, J, n & 3};
+#endif
+}
+// position of fragment (I <= J, s) in consumption order (host-side packing and tests)
+__host__ __device__ constexpr int frag_index(int I, int J, int s, int NB) {
+#if GP_PAIRED
+  for (int n = 0; n < frag_count(NB); ++n) {
+    const FragId f = frag_at(n, NB);
+    if (f.I == I && f.J == J && f.s == s) return n;
+  }
+  return -1;
+#else
+  (void)NB;
+  return (J * (J + 1) / 2 + I) * 4 + s;
+#endif
 }
 // The packed fragment buffer is padded to whole chunks so staging needs no bounds checks.
 __host__ __device__ constexpr int frag_count_padded(int NB, int chunk) {
@@ -533,7 +567,8 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 
     // ---------------- phase B: variance on the matrix core -----------------
     T vacc = T(0);
-    acc_t acc;
+    acc_t acc, acc2;   // acc2: second chain (odd column block of a pair) when GP_PAIRED
+    (void)acc2;
 #if GP_ABLATE == 1
     static_for<4 * NB>([&](auto qc) { vacc += kv[decltype(qc)::value]; });
     static_for<0>([&](auto fc) {
@@ -542,20 +577,28 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 #endif
       constexpr int f = decltype(fc)::value;
       constexpr int c = f / kChunk, fl = f % kChunk;
-      constexpr int pair = f >> 2, s = f & 3;
-      constexpr int J = pair_col(pair);
-      constexpr int I = pair - J * (J + 1) / 2;
+      constexpr FragId fid = frag_at(f, NB);
+      constexpr int I = fid.I, J = fid.J, s = fid.s;
       if constexpr (fl == 0) {
         dma_wait();       // this wave's pieces of chunk c have landed
         __syncthreads();  // chunk c visible; everyone finished reading chunk c-1
         if constexpr (c + 1 < NCH)
           stage_chunk<T>(frags + (c + 1) * kChunk * 64, &s_fr[(c + 1) & 1][0], wave, lane);
       }
-      if constexpr (I == 0 && s == 0) acc = acc_t{T(0), T(0), T(0), T(0)};
-      acc = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc);
-      if constexpr (I == J && s == 3) {
+      if constexpr (GP_PAIRED && (J & 1)) {
+        if constexpr (I == 0 && s == 0) acc2 = acc_t{T(0), T(0), T(0), T(0)};
+        acc2 = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc2);
+        if constexpr (I == J && s == 3) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vacc = fma(acc[r], kv[4 * J + r], vacc);
+          for (int r = 0; r < 4; ++r) vacc = fma(acc2[r], kv[4 * J + r], vacc);
+        }
+      } else {
+        if constexpr (I == 0 && s == 0) acc = acc_t{T(0), T(0), T(0), T(0)};
+        acc = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc);
+        if constexpr (I == J && s == 3) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vacc = fma(acc[r], kv[4 * J + r], vacc);
+        }
       }
     });
     rbuf ^= 1;

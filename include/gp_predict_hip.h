@@ -174,6 +174,8 @@ int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const voi
 /* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  xa and frags
  * are sized by gp_pack_sizes; sd takes 2*kernel_d + 1 reals (sqrt(e_d), the centre c_d, b);
  * used by the CPU tests to check the fragment layout. */
+/* position (in units of 64-real fragments) of fragment (I <= J, k-step s) in the packed buffer */
+int gp_frag_index(int kernel_nb, int I, int J, int s);
 int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,
                   int64_t* xa_len, int64_t* frags_len);
 int gp_pack_model_f64(const double* expX, const double* inputs, const double* invQt,

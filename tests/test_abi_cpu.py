@@ -89,7 +89,7 @@ def test_packed_fragments_reproduce_quadratic_form(name, dtype):
         acc = np.zeros((16, 16))                              # [row j_local][col m]
         for I in range(J + 1):
             for s in range(4):
-                f = frags[(J * (J + 1) // 2 + I) * 4 + s]
+                f = frags[_lib.load().gp_frag_index(nb, I, J, s)]
                 A = np.zeros((16, 4))
                 A[col, grp] = f                               # A[row = l&15][k = l>>4]
                 i_of_k = np.array([16 * I + own(s, gq) for gq in range(4)])
