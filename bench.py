@@ -40,6 +40,27 @@ PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
 
+def synthetic_inputs(seed, n_train, n_inputs, n_predict):
+    """The seeded form of the reference benchmark's inputs (tests/benchmark.py:11-15,28-29):
+    U[0,1) training inputs, test rows, theta, invQ (deliberately non-symmetric), invQt, drawn
+    in that order.  Same recipe as the fixtures' (oracle.gp_oracle.benchmark_inputs), restated
+    here so that the timed path depends on nothing under oracle/."""
+    rs = np.random.RandomState(seed)
+    inputs = rs.random_sample((n_train, n_inputs))
+    testing = rs.random_sample((n_predict, n_inputs))
+    theta = rs.random_sample(n_inputs + 2)
+    invQ = rs.random_sample((n_train, n_train))
+    invQt = rs.random_sample(n_train)
+    return inputs, testing, theta, invQ, invQt
+
+
+def maxnorm_err(ref, got):
+    """max|ref-got| / max|ref| (tests/benchmark.py:51-53)."""
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return float(np.max(np.abs(ref - got)) / np.max(np.abs(ref)))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,8 +83,7 @@ def cpu_baseline(sample_rows):
     (scipy cdist + numpy; BLAS threads = all cores for the np.dot calls, everything else
     single-threaded -- exactly how the reference runs it)."""
     from oracle import gp_oracle
-    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(12345, N_TRAIN, N_INPUTS,
-                                                                     sample_rows)
+    inputs, testing, theta, invQ, invQt = synthetic_inputs(12345, N_TRAIN, N_INPUTS, sample_rows)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -165,7 +185,6 @@ def main():
     if a.workload == "mv":
         return bench_reconstruct(a)
     from gp_emulator_amd import _lib, multi_gpu
-    from oracle import gp_oracle  # inputs recipe, parity spot check, cpu_baseline leg only
 
     grp = multi_gpu.RankGroup()
     rank, world = grp.rank, grp.world
@@ -182,7 +201,7 @@ def main():
     isz = np.dtype(dtype).itemsize
     M = a.n_test or m_default
     E = a.emulators if kind == "batch" else 1
-    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1000 + rank, N, D, M)
+    inputs, testing, theta, invQ, invQt = synthetic_inputs(1000 + rank, N, D, M)
     d_t = ctx.to_device(testing.astype(dtype))
     if kind == "batch":
         # shared inputs / test rows; per-emulator theta, invQ, invQt from seed + e
@@ -236,13 +255,15 @@ def main():
 
     # parity spot check of what was timed (after the timed region: the numpy check leaves
     # BLAS worker threads spinning, which would steal host time from the launch loop)
+    # (the oracle enters only here, as the checker, and in the cpu_baseline leg)
+    from oracle import gp_oracle
     rs = np.random.RandomState(5)
     tol = 1e-10 if a.precision == "f64" else 1e-4
     if kind == "hessian":
         idx = np.sort(rs.choice(M, 256, replace=False))
         got = ctx.to_host(d_h, (M, D, D), dtype)[idx]
         ref = gp_oracle.hessian(inputs, theta, invQt, testing[idx])
-        errs = [gp_oracle.maxnorm_err(ref, got)]
+        errs = [maxnorm_err(ref, got)]
         names = ["e_hess"]
     else:
         idx = rs.choice(M, 2048, replace=False)
@@ -259,10 +280,10 @@ def main():
         else:
             th_c, iq_c, iqt_c = theta, invQ, invQt
         ref = gp_oracle.cpu_predict(inputs, th_c, iq_c, iqt_c, testing[idx])
-        errs = [gp_oracle.maxnorm_err(ref[0], mu), gp_oracle.maxnorm_err(ref[1], var)]
+        errs = [maxnorm_err(ref[0], mu), maxnorm_err(ref[1], var)]
         names = ["e_mu", "e_var"]
         if der is not None:
-            errs.append(gp_oracle.maxnorm_err(ref[2], der))
+            errs.append(maxnorm_err(ref[2], der))
             names.append("e_deriv")
     if not max(errs) <= tol and not a.no_parity:
         raise SystemExit("bench parity check failed: %s" % dict(zip(names, errs)))
