@@ -16,8 +16,9 @@ twelve-argument boundary the reference crosses at :313-316).  It never falls bac
 CPU: if the library or the GPU is missing it raises ``GpuPredictUnavailable``.
 ``is_gpu=False`` is the reference API's explicit numpy branch and is only taken when the
 caller asks for it.  Training (``learn_hyperparameters``, ``loglikelihood``,
-``partial_devs``, :77-125,141-209) is out of scope of this package (SURVEY.md section 8);
-``_set_params`` is kept because it produces the hot path's inputs.
+``partial_devs``, :77-125,141-209) is SURVEY.md section 8(f) rank 2, the first thing after
+the predict path: the objective and its gradient run on the GPU (``is_gpu=True``,
+``csrc/gp_train_kernel.hpp``), the L-BFGS-B driver stays scipy on the host.
 
 Unlike the reference (:7) this module does not import the GPU extension at import time.
 """
@@ -62,6 +63,96 @@ class GaussianProcess:
         """Set hyper-parameters and precompute what predict needs (reference :127-139)."""
         self.theta = theta
         self._prepare_likelihood()
+
+    # ------------------------------------------------------------------ training objective
+    def loglikelihood(self, theta, is_gpu=False):
+        """The reference's cost (negative log marginal likelihood, reference :77-95):
+        0.5 logdetQ + 0.5 t.invQt + 0.5 n log(2 pi).  Like the reference it leaves the
+        object set to ``theta`` (invQ, invQt ready for predict).  ``is_gpu=True`` evaluates
+        cost, gradient, invQ and invQt in one launch of the HIP likelihood kernel
+        (``gp_likelihood_batch_f64``) and keeps the gradient for ``partial_devs``."""
+        theta = np.asarray(theta, dtype=np.float64)
+        if is_gpu == True:  # noqa: E712
+            from . import _lib
+            ctx = _lib.default_context(0)
+            cost, grad, invQ, invQt = ctx.likelihood_batch(theta[None, :], self.inputs,
+                                                           self.targets, want_inverse=True)
+            self.theta = theta
+            self.invQ, self.invQt = invQ[0], invQt[0]
+            self._gpu_models = {}
+            self._last_grad = (theta.copy(), grad[0])
+            loglikelihood = float(cost[0])
+        else:
+            self._set_params(theta)
+            loglikelihood = (0.5 * self.logdetQ + 0.5 * np.dot(self.targets, self.invQt) +
+                             0.5 * self.n * np.log(2. * np.pi))
+        self.current_theta = theta
+        self.current_loglikelihood = loglikelihood
+        return loglikelihood
+
+    def partial_devs(self, theta, is_gpu=False):
+        """Gradient of the cost w.r.t. the D+2 hyper-parameters (reference :97-125).  As in the
+        reference it is evaluated at the state the last ``loglikelihood`` call left; the GPU
+        branch returns the gradient that call already produced (re-evaluating if ``theta``
+        differs)."""
+        if is_gpu == True:  # noqa: E712
+            last = getattr(self, "_last_grad", None)
+            if last is None or not np.array_equal(last[0], np.asarray(theta, dtype=np.float64)):
+                self.loglikelihood(theta, is_gpu=True)
+                last = self._last_grad
+            return last[1].copy()
+        x = np.asarray(self.inputs, dtype=np.float64)
+        partial_d = np.zeros(self.D + 2)
+        for d in range(self.D):
+            col = x[:, d]
+            V = ((col[None, :] - col[:, None]) ** 2) * self.Z
+            partial_d[d] = np.exp(self.theta[d]) * (
+                np.dot(self.invQt, np.dot(V, self.invQt)) - np.sum(self.invQ * V)) / 4.
+        partial_d[self.D] = 0.5 * np.sum(self.invQ * self.Z) - \
+            0.5 * np.dot(self.invQt, np.dot(self.Z, self.invQt))
+        e_noise = np.exp(self.theta[self.D + 1])
+        partial_d[self.D + 1] = 0.5 * np.trace(self.invQ) * e_noise - \
+            0.5 * np.dot(self.invQt, self.invQt) * e_noise
+        return partial_d
+
+    def _learn(self, theta0, verbose, is_gpu=False):
+        """One L-BFGS-B minimisation from ``theta0`` (reference :141-181: factr=0.1,
+        pgtol=1e-20; a LinAlgError returns the last point with cost 9999)."""
+        import warnings
+        from scipy.optimize import fmin_l_bfgs_b
+        iprint = 1 if verbose else -1
+        try:
+            if is_gpu:
+                def both(th):
+                    f = self.loglikelihood(th, is_gpu=True)
+                    return f, self.partial_devs(th, is_gpu=True)
+                theta_opt = fmin_l_bfgs_b(both, theta0, factr=0.1, pgtol=1e-20, iprint=iprint)
+            else:
+                theta_opt = fmin_l_bfgs_b(self.loglikelihood, theta0, fprime=self.partial_devs,
+                                          factr=0.1, pgtol=1e-20, iprint=iprint)
+        except np.linalg.LinAlgError:
+            warnings.warn("Optimisation resulted in linear algebra error. Returning last "
+                          "loglikelihood calculated, but this is fishy", RuntimeWarning)
+            theta_opt = [self.current_theta, 9999]
+        return theta_opt
+
+    def learn_hyperparameters(self, n_tries=15, verbose=False, is_gpu=False):
+        """Fit the hyper-parameters from ``n_tries`` random starts ``5 (rand - 0.5)`` and keep
+        the best (reference :183-209).  Returns ``(cost, theta)`` and leaves the object set to
+        it.  With ``is_gpu=True`` every cost/gradient evaluation is one launch of the HIP
+        likelihood kernel."""
+        log_like = []
+        params = []
+        for theta in 5. * (np.random.rand(n_tries, self.D + 2) - 0.5):
+            T = self._learn(theta, verbose, is_gpu=is_gpu)
+            log_like.append(T[1])
+            params.append(T[0])
+        log_like = np.array(log_like)
+        idx = np.argsort(log_like)[0]
+        if verbose:
+            print("After %d, the minimum cost was %e" % (n_tries, log_like[idx]))
+        self.loglikelihood(params[idx], is_gpu=is_gpu)
+        return (log_like[idx], params[idx])
 
     # ------------------------------------------------------------------ numpy branch
     def cpu_predict(self, testing, do_unc=True):

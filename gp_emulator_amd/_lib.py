@@ -53,6 +53,8 @@ SIGNATURES = {
     "gp_hessian_f32": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_reconstruct_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int]),
     "gp_frag_index": (c_int, [c_int, c_int, c_int, c_int]),
+    "gp_likelihood_batch_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gp_pack_sizes": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                               ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "gp_pack_model_f64": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),
@@ -181,6 +183,28 @@ class Context:
         code = GP_F64 if np.dtype(dtype) == np.float64 else GP_F32
         check(self.lib.gp_reconstruct_device(self.h, code, d_basis, d_coef, d_out, int(n_rows),
                                              int(n_pcs), int(n_bands)), "gp_reconstruct_device")
+
+    def likelihood_batch(self, thetas, inputs, targets, want_inverse=False):
+        """cost (E,), grad (E, D+2) [and invQ (E, N, N), invQt (E, N)] of the training
+        objective for E hyper-parameter sets; targets (N,) shared or (E, N)."""
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        inputs = np.ascontiguousarray(inputs, dtype=np.float64)
+        targets = np.ascontiguousarray(targets, dtype=np.float64)
+        E, N, D = thetas.shape[0], inputs.shape[0], inputs.shape[1]
+        if thetas.shape[1] != D + 2:
+            raise ValueError("theta needs n_inputs + 2 entries")
+        shared = targets.ndim == 1
+        if targets.shape[-1] != N or (not shared and targets.shape[0] != E):
+            raise ValueError("targets must be (n_train,) or (n_sets, n_train)")
+        cost = np.empty(E)
+        grad = np.empty((E, D + 2))
+        invQ = np.empty((E, N, N)) if want_inverse else None
+        invQt = np.empty((E, N)) if want_inverse else None
+        check(self.lib.gp_likelihood_batch_f64(
+            self.h, E, _ptr(thetas), _ptr(inputs), _ptr(targets), int(shared), N, D, _ptr(cost),
+            _ptr(grad), _ptr(invQ) if want_inverse else None,
+            _ptr(invQt) if want_inverse else None), "gp_likelihood_batch_f64")
+        return (cost, grad, invQ, invQt) if want_inverse else (cost, grad)
 
     # ---- events -----------------------------------------------------------------
     def event(self):

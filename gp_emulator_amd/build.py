@@ -90,6 +90,8 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
                                         os.path.join(CSRC, "gp_hessian_tu.hip"), "-o", obj])
     tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_reconstruct_tu.hip"),
                                            "-o", os.path.join(OBJ, "reconstruct.o")])
+    tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_train_tu.hip"),
+                                           "-o", os.path.join(OBJ, "train.o")])
     abi_obj = os.path.join(OBJ, "gp_abi.o")
     tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_abi.hip"), "-o", abi_obj])
     # biggest kernels first so the pool drains evenly

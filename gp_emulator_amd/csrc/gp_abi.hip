@@ -18,8 +18,10 @@
 #include "gp_hessian_kernel.hpp"
 #include "gp_predict_kernel.hpp"
 #include "gp_reconstruct_kernel.hpp"
+#include "gp_train_args.hpp"
 
 namespace gpk {
+hipError_t launch_likelihood(const TrainArgs&, int n_sets, hipStream_t);
 hipError_t launch_reconstruct_f32(const ReconArgs<float>&, int wide, int cus, hipStream_t);
 hipError_t launch_reconstruct_f64(const ReconArgs<double>&, int wide, int cus, hipStream_t);
 hipError_t launch_generic_f32(const GenericArgs<float>&, int, hipStream_t);
@@ -878,6 +880,47 @@ int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const voi
     e = gpk::launch_reconstruct_f32(a, wide, ctx->compute_units, ctx->stream);
   }
   if (e != hipSuccess) return fail(GP_ERR_HIP, "reconstruct kernel launch: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
+int gp_likelihood_batch_f64(gp_ctx* ctx, int n_sets, const double* theta, const double* inputs,
+                            const double* targets, int targets_shared, int n_train, int n_inputs,
+                            double* cost, double* grad, double* invQ, double* invQt) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  if (!theta || !inputs || !targets || !cost || !grad) return fail(GP_ERR_INVALID, "null pointer");
+  if (n_sets <= 0 || n_train <= 0 || n_inputs <= 0) return fail(GP_ERR_INVALID, "bad sizes");
+  if (n_train > gpk::tkMaxN || n_inputs > gpk::tkMaxD)
+    return fail(GP_ERR_UNSUPPORTED, "likelihood kernel is compiled for n_train <= %d, n_inputs <= %d",
+                gpk::tkMaxN, gpk::tkMaxD);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t E = (size_t)n_sets, N = (size_t)n_train, D = (size_t)n_inputs;
+  const size_t n_theta = E * (D + 2), n_in = N * D, n_tg = (targets_shared ? 1 : E) * N;
+  const size_t n_work = E * N * N, n_qt = E * N, n_cost = E, n_grad = E * (D + 2);
+  int rc = ensure_scratch(ctx, sizeof(double) * (n_theta + n_in + n_tg + n_work + n_qt + n_cost + n_grad));
+  if (rc) return rc;
+  double* d_theta = (double*)ctx->scratch;
+  double* d_in = d_theta + n_theta;
+  double* d_tg = d_in + n_in;
+  double* d_work = d_tg + n_tg;
+  double* d_qt = d_work + n_work;
+  double* d_cost = d_qt + n_qt;
+  double* d_grad = d_cost + n_cost;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(d_theta, theta, sizeof(double) * n_theta, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_in, inputs, sizeof(double) * n_in, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_tg, targets, sizeof(double) * n_tg, hipMemcpyHostToDevice, st));
+  gpk::TrainArgs a;
+  a.theta = d_theta; a.inputs = d_in; a.targets = d_tg;
+  a.targets_stride = targets_shared ? 0 : (long long)N;
+  a.work = d_work; a.invQt = d_qt; a.cost = d_cost; a.grad = d_grad;
+  a.N = n_train; a.D = n_inputs;
+  hipError_t e = gpk::launch_likelihood(a, n_sets, st);
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "likelihood kernel launch: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(cost, d_cost, sizeof(double) * n_cost, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(grad, d_grad, sizeof(double) * n_grad, hipMemcpyDeviceToHost, st));
+  if (invQt) HIP_TRY(hipMemcpyAsync(invQt, d_qt, sizeof(double) * n_qt, hipMemcpyDeviceToHost, st));
+  if (invQ) HIP_TRY(hipMemcpyAsync(invQ, d_work, sizeof(double) * n_work, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return GP_OK;
 }
 

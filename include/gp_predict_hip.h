@@ -171,6 +171,17 @@ int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const fl
 int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const void* d_coef,
                           void* d_out, int64_t n_rows, int n_pcs, int n_bands);
 
+/* ---- training objective (next after the predict path: SURVEY.md 8f rank 2) -------------------
+ * For each of n_sets hyper-parameter vectors theta [n_sets][n_inputs+2]: what
+ * GaussianProcess.loglikelihood + partial_devs compute (gp_emulator/GaussianProcess.py:52-125):
+ * cost [n_sets], grad [n_sets][n_inputs+2], and optionally the by-products of
+ * _prepare_likelihood, invQ [n_sets][n_train^2] and invQt [n_sets][n_train] (NULL to skip).
+ * targets is [n_train] when targets_shared != 0 (random restarts of one emulator), else
+ * [n_sets][n_train] (per-band emulators).  Host pointers, fp64 only, synchronous. */
+int gp_likelihood_batch_f64(gp_ctx* ctx, int n_sets, const double* theta, const double* inputs,
+                            const double* targets, int targets_shared, int n_train, int n_inputs,
+                            double* cost, double* grad, double* invQ, double* invQt);
+
 /* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  xa and frags
  * are sized by gp_pack_sizes; sd takes 2*kernel_d + 1 reals (sqrt(e_d), the centre c_d, b);
  * used by the CPU tests to check the fragment layout. */

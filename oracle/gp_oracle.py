@@ -45,6 +45,34 @@ def prepare_likelihood(inputs, targets, theta):
     return dict(Z=Z, Q=Q, invQ=invQ, invQt=invQt, logdetQ=logdetQ)
 
 
+def loglikelihood(inputs, targets, theta):
+    """Negative log marginal likelihood as the reference defines its cost,
+    gp_emulator/GaussianProcess.py:77-95: 0.5 logdetQ + 0.5 t.invQt + 0.5 n log(2 pi)."""
+    pl = prepare_likelihood(inputs, targets, theta)
+    n = np.asarray(inputs).shape[0]
+    return (0.5 * pl["logdetQ"] + 0.5 * np.dot(targets, pl["invQt"]) +
+            0.5 * n * np.log(2. * np.pi))
+
+
+def partial_devs(inputs, targets, theta):
+    """Gradient of that cost w.r.t. the D+2 hyper-parameters,
+    gp_emulator/GaussianProcess.py:97-125 (V built with np.tile exactly as there)."""
+    inputs = np.asarray(inputs)
+    n, D = inputs.shape
+    pl = prepare_likelihood(inputs, targets, theta)
+    Z, invQ, invQt = pl["Z"], pl["invQ"], pl["invQt"]
+    partial_d = np.zeros(D + 2)
+    for d in range(D):
+        V = (((np.tile(inputs[:, d], (n, 1)) -
+               np.tile(inputs[:, d], (n, 1)).T)) ** 2).T * Z
+        partial_d[d] = np.exp(theta[d]) * \
+            (np.dot(invQt, np.dot(V, invQt)) - np.sum(invQ * V)) / 4.
+    partial_d[D] = 0.5 * np.sum(invQ * Z) - 0.5 * np.dot(invQt, np.dot(Z, invQt))
+    partial_d[D + 1] = 0.5 * np.trace(invQ) * np.exp(theta[D + 1]) - \
+        0.5 * np.dot(invQt, invQt) * np.exp(theta[D + 1])
+    return partial_d
+
+
 def kernel_rows(inputs, theta, testing):
     """K_*^T, shape (N_train, N_test).  gp_emulator/GaussianProcess.py:230-234."""
     D = inputs.shape[1]

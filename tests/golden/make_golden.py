@@ -132,6 +132,33 @@ def main():
           float(np.max(np.abs(pl["invQ"] - gp0.invQ))),
           float(np.max(np.abs(pl["invQt"] - gp0.invQt))))
 
+    # ---- training objective (reference :77-125), from the reference's own methods -------
+    train = {}
+    gpt = mods["GaussianProcess"].GaussianProcess(y_train, train_data[0])
+    th = hyper[:, 0]
+    train["prosail_pc0_theta"] = th
+    train["prosail_pc0_loglik"] = gpt.loglikelihood(th)
+    train["prosail_pc0_grad"] = gpt.partial_devs(th)
+    rs2 = np.random.RandomState(4242)
+    Xs = rs2.random_sample((120, 4))
+    ts = np.sin(3 * Xs[:, 0]) + Xs[:, 1] ** 2 - 0.5 * Xs[:, 2] * Xs[:, 3]
+    gps = mods["GaussianProcess"].GaussianProcess(Xs, ts)
+    thetas = np.array([[0.3, -0.2, 0.1, 0.4, 0.5, -3.0], [1.0, 0.5, -0.5, 0.0, 0.0, -6.0],
+                       [-1.0, -1.0, -1.0, -1.0, 1.0, -1.0]])
+    train["smooth_inputs"], train["smooth_targets"], train["smooth_thetas"] = Xs, ts, thetas
+    # partial_devs(theta) reads the state left by the last loglikelihood/_set_params call and
+    # ignores its argument's value for Z/invQ (reference :97-125), as L-BFGS calls them in
+    # that order at one point; so evaluate the pair per theta
+    ll, gr = [], []
+    for t in thetas:
+        ll.append(gps.loglikelihood(t))
+        gr.append(gps.partial_devs(t))
+    train["smooth_loglik"], train["smooth_grad"] = np.array(ll), np.array(gr)
+    np.savez_compressed(os.path.join(out, "training_objective.npz"), **train)
+    print("training objective vs oracle:",
+          float(abs(gp_oracle.loglikelihood(y_train, train_data[0], th) - train["prosail_pc0_loglik"])),
+          float(np.max(np.abs(gp_oracle.partial_devs(Xs, ts, thetas[0]) - train["smooth_grad"][0]))))
+
     # MultivariateEmulator.predict known answers (single test point API,
     # gp_emulator/multivariate_gp.py:195-222)
     pts = np.vstack([y_train[0], y_train[17], testing[0], testing[1]])

@@ -222,3 +222,27 @@ def test_multivariate_emulator_cpu_matches_reference_outputs(tmp_path):
         assert sorted(f.files) == ["X", "basis_functions", "hyperparams", "n_pcs", "thresh", "y"]
     with pytest.raises(NotImplementedError):
         MultivariateEmulator(X=mv.X_train, y=mv.y_train)
+
+
+def test_host_training_objective_numpy_branch():
+    from conftest import load_golden
+    g = load_golden("training_objective")
+    gp = GaussianProcess(g["smooth_inputs"], g["smooth_targets"])
+    for k in range(3):
+        ll = gp.loglikelihood(g["smooth_thetas"][k])
+        gr = gp.partial_devs(g["smooth_thetas"][k])
+        assert abs(ll - g["smooth_loglik"][k]) <= 1e-9 * abs(g["smooth_loglik"][k])
+        assert np.max(np.abs(gr - g["smooth_grad"][k])) <= 1e-7 * np.max(np.abs(g["smooth_grad"][k]))
+    # noisy targets, so that the optimum is interior (with the noiseless ones the reference's
+    # own optimiser drives the noise term to 0 until Cholesky fails and reports cost 9999)
+    noisy = g["smooth_targets"] + 0.05 * np.random.RandomState(1).standard_normal(120)
+    gp = GaussianProcess(g["smooth_inputs"], noisy)
+    np.random.seed(1)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cost, theta = gp.learn_hyperparameters(n_tries=2)
+    assert theta.shape == (6,) and abs(cost - (-148.607048555)) < 1e-5
+    assert np.max(np.abs(gp.partial_devs(theta))) < 1e-3
+    mu, var, der = gp.predict(g["smooth_inputs"][:5])
+    assert np.max(np.abs(mu - g["smooth_targets"][:5])) < 0.1

@@ -500,3 +500,54 @@ def test_predict_sharded_threads_on_gpu(gpu_lib):
     one = gp.gpu_model(np.float64).predict(g["testing"])
     for a, b in zip(one, (mu, var, der)):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------
+# training objective on the GPU (reference GaussianProcess.py:52-125)
+# ---------------------------------------------------------------------------------------
+def test_likelihood_kernel_matches_reference(gpu_lib):
+    g = load_golden("training_objective")
+    ctx = _lib.default_context(0)
+    cost, grad, invQ, invQt = ctx.likelihood_batch(g["smooth_thetas"], g["smooth_inputs"],
+                                                   g["smooth_targets"], want_inverse=True)
+    for k in range(3):
+        assert abs(cost[k] - g["smooth_loglik"][k]) <= 1e-9 * abs(g["smooth_loglik"][k])
+        assert np.max(np.abs(grad[k] - g["smooth_grad"][k])) <= 1e-6 * np.max(np.abs(g["smooth_grad"][k]))
+        pl = gp_oracle.prepare_likelihood(g["smooth_inputs"], g["smooth_targets"], g["smooth_thetas"][k])
+        assert np.max(np.abs(invQ[k] - pl["invQ"])) <= 1e-7 * np.max(np.abs(pl["invQ"]))
+        assert np.max(np.abs(invQt[k] - pl["invQt"])) <= 1e-7 * np.max(np.abs(pl["invQt"]))
+    # the real emulator (cond ~1e7): N = 250, D = 10
+    p = load_golden("prosail_pc0")
+    c1, g1 = ctx.likelihood_batch(g["prosail_pc0_theta"], p["inputs"], p["targets"])
+    assert abs(c1[0] - g["prosail_pc0_loglik"]) <= 1e-8 * abs(g["prosail_pc0_loglik"])
+    assert np.max(np.abs(g1[0] - g["prosail_pc0_grad"])) <= 1e-4 * np.max(np.abs(g["prosail_pc0_grad"]))
+    # per-set targets (per-band pattern): E sets, each with its own targets
+    E = 5
+    rs = np.random.RandomState(0)
+    tg = np.stack([g["smooth_targets"] * (1 + 0.1 * e) + 0.01 * rs.standard_normal(120) for e in range(E)])
+    th = np.tile(g["smooth_thetas"][0], (E, 1)) + 0.05 * rs.standard_normal((E, 6))
+    cE, gE = ctx.likelihood_batch(th, g["smooth_inputs"], tg)
+    for e in range(E):
+        assert abs(cE[e] - gp_oracle.loglikelihood(g["smooth_inputs"], tg[e], th[e])) <= 1e-8 * abs(cE[e])
+        ref = gp_oracle.partial_devs(g["smooth_inputs"], tg[e], th[e])
+        assert np.max(np.abs(gE[e] - ref)) <= 1e-6 * np.max(np.abs(ref))
+
+
+def test_learn_hyperparameters_on_gpu(gpu_lib):
+    """learn_hyperparameters(is_gpu=True): scipy's L-BFGS-B driving the HIP objective reaches
+    the same optimum as the numpy branch, and the fitted emulator predicts on the GPU."""
+    import warnings
+    g = load_golden("training_objective")
+    noisy = g["smooth_targets"] + 0.05 * np.random.RandomState(1).standard_normal(120)
+    gp = GaussianProcess(g["smooth_inputs"], noisy)
+    np.random.seed(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cost, theta = gp.learn_hyperparameters(n_tries=2, is_gpu=True)
+    assert abs(cost - (-148.607048555)) < 1e-4
+    ref = gp_oracle.cpu_predict(g["smooth_inputs"], gp.theta, gp.invQ, gp.invQt, g["smooth_inputs"][:50])
+    got = gp.predict(g["smooth_inputs"][:50], is_gpu=True)
+    e = errs(ref, got)
+    assert e[0] <= 1e-10 and e[2] <= 1e-10
+    b = float(np.exp(gp.theta[4]))          # trained emulator: var cancels, judge it against b
+    assert np.max(np.abs(ref[1] - got[1])) / b <= 1e-8

@@ -108,3 +108,27 @@ def test_multivariate_known_answer():
         assert np.max(np.abs(jac - g["jac"][j])) / np.max(np.abs(g["jac"][j])) <= 1e-6
     fwd0, _ = gp_oracle.multivariate_predict(g["basis_functions"], emus, g["points"][0])
     assert np.max(np.abs(fwd0 - g["x_train_row0"])) <= 2e-3
+
+
+def test_training_objective_matches_reference():
+    """loglikelihood / partial_devs restatement against the reference's own methods
+    (gp_emulator/GaussianProcess.py:77-125; goldens in training_objective.npz)."""
+    g = load_golden("training_objective")
+    for k in range(len(g["smooth_thetas"])):
+        ll = gp_oracle.loglikelihood(g["smooth_inputs"], g["smooth_targets"], g["smooth_thetas"][k])
+        gr = gp_oracle.partial_devs(g["smooth_inputs"], g["smooth_targets"], g["smooth_thetas"][k])
+        assert abs(ll - g["smooth_loglik"][k]) <= 1e-9 * abs(g["smooth_loglik"][k])
+        assert np.max(np.abs(gr - g["smooth_grad"][k])) <= 1e-7 * np.max(np.abs(g["smooth_grad"][k]))
+    p = load_golden("prosail_pc0")
+    ll = gp_oracle.loglikelihood(p["inputs"], p["targets"], g["prosail_pc0_theta"])
+    assert abs(ll - g["prosail_pc0_loglik"]) <= 1e-8 * abs(g["prosail_pc0_loglik"])
+    # the gradient is the derivative of the cost (central differences)
+    th = g["smooth_thetas"][0]
+    gr = gp_oracle.partial_devs(g["smooth_inputs"], g["smooth_targets"], th)
+    for d in range(len(th)):
+        tp, tm = th.copy(), th.copy()
+        tp[d] += 1e-5
+        tm[d] -= 1e-5
+        fd = (gp_oracle.loglikelihood(g["smooth_inputs"], g["smooth_targets"], tp) -
+              gp_oracle.loglikelihood(g["smooth_inputs"], g["smooth_targets"], tm)) / 2e-5
+        assert abs(fd - gr[d]) <= 1e-5 * max(1.0, abs(gr[d]))
