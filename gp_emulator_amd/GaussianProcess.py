@@ -143,8 +143,22 @@ class GaussianProcess:
         likelihood kernel."""
         log_like = []
         params = []
-        for theta in 5. * (np.random.rand(n_tries, self.D + 2) - 0.5):
-            T = self._learn(theta, verbose, is_gpu=is_gpu)
+        starts = 5. * (np.random.rand(n_tries, self.D + 2) - 0.5)
+        if is_gpu and n_tries > 1:
+            # one evaluation keeps a single workgroup busy, so the restarts run side by side:
+            # a host thread, a context (stream) and a private copy of this object per restart
+            import copy
+            from concurrent.futures import ThreadPoolExecutor
+
+            def one(theta0):
+                worker = copy.copy(self)
+                worker._gpu_models = {}
+                return worker._learn(theta0, verbose, is_gpu=True)
+            with ThreadPoolExecutor(max_workers=min(n_tries, 8)) as ex:
+                results = list(ex.map(one, starts))
+        else:
+            results = [self._learn(theta, verbose, is_gpu=is_gpu) for theta in starts]
+        for T in results:
             log_like.append(T[1])
             params.append(T[0])
         log_like = np.array(log_like)
