@@ -6,8 +6,13 @@ namespace gpk {
 
 constexpr int tkSide = 32;                  // 32 x 32 thread tile
 constexpr int tkThreads = tkSide * tkSide;
-constexpr int tkMaxN = 512;                 // LDS: pivot row + column factors + targets
+constexpr int tkMaxN = 512;                 // LDS: 8 (2 tkB + D) N bytes dynamic + 3 N reals static
 constexpr int tkMaxD = 16;
+#ifndef GP_TK_U
+#define GP_TK_U 4
+#endif
+constexpr int tkU = GP_TK_U;                // columns per thread per trip of the update loop
+constexpr int tkB = 8;                      // pivots per elimination pass
 
 struct TrainArgs {
   const double* theta;     // [E][D + 2]
@@ -20,5 +25,10 @@ struct TrainArgs {
   double* grad;            // [E][D + 2]
   int N, D;
 };
+
+// dynamic LDS of one workgroup: pivot rows, W, transposed inputs
+inline unsigned long likelihood_lds_bytes(int N, int D) {
+  return sizeof(double) * (unsigned long)N * (2 * tkB + D);
+}
 
 }  // namespace gpk

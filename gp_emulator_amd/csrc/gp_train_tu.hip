@@ -3,8 +3,31 @@
 
 namespace gpk {
 
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t lds) {
+  if (lds <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+}
+
 hipError_t launch_likelihood(const TrainArgs& a, int n_sets, hipStream_t stream) {
-  hipLaunchKernelGGL(likelihood_kernel, dim3(n_sets), dim3(tkSide, tkSide), 0, stream, a);
+  const size_t lds = likelihood_lds_bytes(a.N, a.D);
+  const size_t lds_grad = sizeof(double) * (size_t)a.N * a.D;
+  const dim3 grid(n_sets), block(tkSide, tkSide);
+  hipError_t e = allow_lds(likelihood_kernel, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(likelihood_kernel, grid, block, lds, stream, a);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+#define GP_GRAD(DM)                                                                  \
+  do {                                                                               \
+    if ((e = allow_lds(likelihood_grad_kernel<DM>, lds_grad)) != hipSuccess) return e; \
+    hipLaunchKernelGGL(likelihood_grad_kernel<DM>, grid, block, lds_grad, stream, a);  \
+  } while (0)
+  if (a.D <= 4) GP_GRAD(4);
+  else if (a.D <= 8) GP_GRAD(8);
+  else if (a.D <= 12) GP_GRAD(12);
+  else GP_GRAD(tkMaxD);
+#undef GP_GRAD
   return hipGetLastError();
 }
 

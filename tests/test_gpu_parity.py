@@ -533,6 +533,29 @@ def test_likelihood_kernel_matches_reference(gpu_lib):
         assert np.max(np.abs(gE[e] - ref)) <= 1e-6 * np.max(np.abs(ref))
 
 
+@pytest.mark.parametrize("n,d", [(1, 1), (3, 2), (8, 2), (9, 3), (16, 2), (37, 3), (120, 4),
+                                 (250, 10), (300, 11), (512, 16)])
+def test_likelihood_kernel_every_panel_shape(gpu_lib, n, d):
+    """The elimination takes 8 pivots per pass: cover a ragged last panel (n % 8 != 0), a single
+    panel, n below the 32 x 32 thread tile and the compiled maxima (512, 16).  Checked against the
+    oracle's numpy route: inverse to 1e-11 of its largest entry (exactly symmetric), cost 1e-11."""
+    rs = np.random.RandomState(n)
+    X = rs.random_sample((n, d))
+    t = np.sin(X.sum(1))
+    th = np.concatenate([0.3 * rs.standard_normal(d), [0.0, -4.0]])
+    ctx = _lib.default_context(0)
+    cost, grad, invQ, invQt = ctx.likelihood_batch(th[None, :], X, t, want_inverse=True)
+    pl = gp_oracle.prepare_likelihood(X, t, th)
+    scale = np.max(np.abs(pl["invQ"]))
+    assert np.max(np.abs(invQ[0] - pl["invQ"])) <= 1e-11 * scale
+    assert np.max(np.abs(invQ[0] - invQ[0].T)) <= 1e-15 * scale
+    assert np.max(np.abs(invQt[0] - pl["invQt"])) <= 1e-10 * np.max(np.abs(pl["invQt"]))
+    ref = gp_oracle.loglikelihood(X, t, th)
+    assert abs(cost[0] - ref) <= 1e-11 * max(1.0, abs(ref))
+    gref = gp_oracle.partial_devs(X, t, th)
+    assert np.max(np.abs(grad[0] - gref)) <= 1e-8 * max(1e-300, np.max(np.abs(gref)))
+
+
 def test_learn_hyperparameters_on_gpu(gpu_lib):
     """learn_hyperparameters(is_gpu=True): scipy's L-BFGS-B driving the HIP objective reaches
     the same optimum as the numpy branch, and the fitted emulator predicts on the GPU."""
