@@ -22,10 +22,25 @@ the predict path: the objective and its gradient run on the GPU (``is_gpu=True``
 
 Unlike the reference (:7) this module does not import the GPU extension at import time.
 """
+import random
+
 import numpy as np
 import scipy.spatial.distance as dist
 
-__all__ = ["GaussianProcess"]
+__all__ = ["GaussianProcess", "k_fold_cross_validation"]
+
+
+def k_fold_cross_validation(X, K, randomise=False):
+    """K (training, validation) partitions of the items of ``X`` (reference :9-26): item i goes
+    to the validation list of fold ``i % K`` and to the training list of every other fold;
+    ``randomise`` shuffles a copy first (``random.shuffle``, the ``random`` module's stream)."""
+    if randomise:
+        X = list(X)
+        random.shuffle(X)
+    for k in range(K):
+        training = [x for i, x in enumerate(X) if i % K != k]
+        validation = [x for i, x in enumerate(X) if i % K == k]
+        yield training, validation
 
 
 class GaussianProcess:
@@ -59,8 +74,14 @@ class GaussianProcess:
         self.logdetQ = 2.0 * np.sum(np.log(np.diag(np.linalg.cholesky(self.Q))))
         self._gpu_models = {}
 
-    def _set_params(self, theta):
-        """Set hyper-parameters and precompute what predict needs (reference :127-139)."""
+    def _set_params(self, theta, is_gpu=False):
+        """Set hyper-parameters and precompute what predict needs (reference :127-139).
+        ``is_gpu=True`` takes invQ and invQt from the HIP likelihood kernel instead of host
+        LAPACK (``Z``, ``Q`` and ``logdetQ``, which only the numpy training branch reads, are
+        then not formed)."""
+        if is_gpu == True:  # noqa: E712
+            self.loglikelihood(theta, is_gpu=True)
+            return
         self.theta = theta
         self._prepare_likelihood()
 

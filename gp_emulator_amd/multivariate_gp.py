@@ -7,9 +7,11 @@ the constructor, ``compress``, ``predict`` and ``dump_emulator`` with the refere
 argument names and return shapes, and loads the reference's ``.npz`` dumps (:68-79,
 e.g. data/prosail_30_0_30_0.npz) with ``allow_pickle=False``.
 
-Out of scope here, as in GaussianProcess.py: training.  ``hyperparams`` must be supplied
-(directly or through ``dump``); the reference's ``learn_hyperparameters`` path (:175-184)
-raises ``NotImplementedError``.
+With ``hyperparams`` (given or from ``dump``) every per-PC emulator is only set up
+(``_set_params``, reference :185-186); without, each one is trained with
+``learn_hyperparameters(n_tries)`` (:180-184).  ``is_gpu=True`` -- a keyword the reference's
+constructor does not have -- does either on the GPU: all n_pcs inverses in ONE launch of the
+likelihood kernel (they share the training inputs), or the GPU training objective.
 """
 import numpy as np
 
@@ -20,10 +22,10 @@ __all__ = ["MultivariateEmulator"]
 
 class MultivariateEmulator(object):
 
-    def __init__(self, dump=None, X=None, y=None, hyperparams=None, thresh=0.98, n_tries=5):
-        # reference :40-122
-        basis_functions = None
-        n_pcs = None
+    def __init__(self, dump=None, X=None, y=None, hyperparams=None, thresh=0.98, n_tries=5,
+                 basis_functions=None, n_pcs=None, is_gpu=False):
+        # reference :40-122; basis_functions / n_pcs: a stored decomposition (what
+        # save_emulators.py:93-98 tries to pass), is_gpu: set up or train on the GPU
         if dump is not None:
             if X is None and y is None:
                 with np.load(dump, allow_pickle=False) as f:
@@ -54,7 +56,7 @@ class MultivariateEmulator(object):
         self.basis_functions = basis_functions
         if hyperparams is not None:
             assert (y.shape[1] + 2 == hyperparams.shape[0]) and (self.n_pcs == hyperparams.shape[1])
-        self.train_emulators(X, y, hyperparams=hyperparams, n_tries=n_tries)
+        self.train_emulators(X, y, hyperparams=hyperparams, n_tries=n_tries, is_gpu=is_gpu)
 
     def dump_emulator(self, fname):
         """Save in the reference's .npz layout (reference :124-137)."""
@@ -72,20 +74,30 @@ class MultivariateEmulator(object):
         self.basis_functions = V[:s.size][pcnt_var_explained <= thresh]
         self.n_pcs = int(np.sum(pcnt_var_explained <= thresh))
 
-    def train_emulators(self, X, y, hyperparams, n_tries=2):
+    def train_emulators(self, X, y, hyperparams, n_tries=2, is_gpu=False):
         """One GaussianProcess per PC on the shared inputs (reference :162-188)."""
-        if hyperparams is None:
-            raise NotImplementedError(
-                "hyper-parameter learning (GaussianProcess.learn_hyperparameters) is outside "
-                "this package's scope; pass hyperparams or a dump file")
         self.emulators = []
         train_data = self.compress(X)
         self.hyperparams = np.zeros((2 + y.shape[1], self.n_pcs))
         for i in range(self.n_pcs):
-            gp = GaussianProcess(np.atleast_2d(y), train_data[i])
-            self.hyperparams[:, i] = hyperparams[:, i]
+            self.emulators.append(GaussianProcess(np.atleast_2d(y), train_data[i]))
+        if hyperparams is None:
+            for i, gp in enumerate(self.emulators):
+                self.hyperparams[:, i] = gp.learn_hyperparameters(n_tries=n_tries, is_gpu=is_gpu)[1]
+            return
+        self.hyperparams[:, :] = np.asarray(hyperparams)[:, :self.n_pcs]
+        if is_gpu and self.n_pcs > 0:
+            # the emulators differ in targets and theta only: one launch, one workgroup each
+            from . import _lib
+            cost, grad, invQ, invQt = _lib.default_context(0).likelihood_batch(
+                self.hyperparams.T, np.atleast_2d(y), train_data, want_inverse=True)
+            for i, gp in enumerate(self.emulators):
+                gp.theta = self.hyperparams[:, i].copy()
+                gp.invQ, gp.invQt = invQ[i], invQt[i]
+                gp.current_theta, gp.current_loglikelihood = gp.theta, float(cost[i])
+            return
+        for i, gp in enumerate(self.emulators):
             gp._set_params(hyperparams[:, i])
-            self.emulators.append(gp)
 
     def compress(self, X):
         """Project full-rank vectors onto the PC basis (reference :190-193)."""

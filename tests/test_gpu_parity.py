@@ -574,3 +574,49 @@ def test_learn_hyperparameters_on_gpu(gpu_lib):
     assert e[0] <= 1e-10 and e[2] <= 1e-10
     b = float(np.exp(gp.theta[4]))          # trained emulator: var cancels, judge it against b
     assert np.max(np.abs(ref[1] - got[1])) / b <= 1e-8
+
+
+# ---------------------------------------------------------------------------------------
+# stored emulators straight onto the device (reference
+# multivariate_gp.py:68-92,162-188 and save_emulators.py:80-106)
+# ---------------------------------------------------------------------------------------
+def test_set_params_on_gpu_matches_host(gpu_lib):
+    p = load_golden("prosail_pc0")
+    gp = GaussianProcess(p["inputs"], p["targets"])
+    gp._set_params(p["theta"], is_gpu=True)
+    scale = np.max(np.abs(p["invQ"]))
+    assert np.max(np.abs(gp.invQ - p["invQ"])) <= 1e-8 * scale      # cond(Q) = 3.5e7
+    assert np.max(np.abs(gp.invQt - p["invQt"])) <= 1e-7 * np.max(np.abs(p["invQt"]))
+    mu, var, der = gp.predict(p["testing"], is_gpu=True)
+    e_mu, e_der = gp_oracle.maxnorm_err(p["mu"], mu), gp_oracle.maxnorm_err(p["deriv"], der)
+    e_var = np.max(np.abs(var - p["var"])) / float(np.exp(p["theta"][10]))
+    print("set_params on gpu: invQ %.2e mu %.2e deriv %.2e var/b %.2e" % (
+        np.max(np.abs(gp.invQ - p["invQ"])) / scale, e_mu, e_der, e_var))
+    assert e_mu <= 1e-8 and e_der <= 1e-8 and e_var <= 1e-7   # numpy's own inverse is 2e-10 off
+
+
+def test_multivariate_set_up_on_gpu_and_storage(gpu_lib, tmp_path):
+    """All n_pcs inverses in one launch; the emulator then predicts as the host-built one does;
+    EmulatorStorage.get_emulator(is_gpu=True) takes the same route."""
+    from gp_emulator_amd import EmulatorStorage, MultivariateEmulator
+    g = load_golden("prosail_mv")
+    rs = np.random.RandomState(0)
+    # a stand-in training set with the real inputs, thetas and basis: X = weights . basis
+    X = g["train_data"].T @ g["basis_functions"]
+    kw = dict(X=X, y=g["y_train"], hyperparams=g["hyperparams"], basis_functions=g["basis_functions"],
+              n_pcs=int(g["n_pcs"]))
+    host = MultivariateEmulator(**kw)
+    dev = MultivariateEmulator(is_gpu=True, **kw)
+    for a, b in zip(host.emulators, dev.emulators):
+        assert np.array_equal(a.theta, b.theta)
+        assert np.max(np.abs(a.invQt - b.invQt)) <= 1e-6 * np.max(np.abs(a.invQt))
+    Y = g["points"]
+    f_host = host.predict_many(Y, is_gpu=True)
+    f_dev = dev.predict_many(Y, is_gpu=True)
+    assert np.max(np.abs(f_host - f_dev)) <= 1e-7 * np.max(np.abs(f_host))
+    store = EmulatorStorage(str(tmp_path / "emus.npz"))
+    store.dump_emulator(dev, ("prosail", 30, 0))
+    back = store.get_emulator(("prosail", 30, 0), is_gpu=True)
+    assert np.max(np.abs(back.predict_many(Y, is_gpu=True) - f_dev)) <= 1e-12 * np.max(np.abs(f_dev))
+    one, jac = back.predict(Y[0], is_gpu=True)
+    assert np.max(np.abs(one - f_dev[0])) <= 1e-10 * np.max(np.abs(f_dev[0]))
