@@ -220,8 +220,6 @@ def test_multivariate_emulator_cpu_matches_reference_outputs(tmp_path):
     mv.dump_emulator(str(out))
     with np.load(str(out), allow_pickle=False) as f:
         assert sorted(f.files) == ["X", "basis_functions", "hyperparams", "n_pcs", "thresh", "y"]
-    with pytest.raises(NotImplementedError):
-        MultivariateEmulator(X=mv.X_train, y=mv.y_train)
 
 
 def test_host_training_objective_numpy_branch():
