@@ -299,24 +299,32 @@ def test_multivariate_emulator_gpu(gpu_lib, tmp_path):
 
 
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
-@pytest.mark.parametrize("P,B,R", [(12, 2101, 1000), (1, 7, 3), (16, 1024, 129), (5, 1025, 128), (9, 300, 257)])
-def test_reconstruct_kernel(gpu_lib, P, B, R, precision):
-    """out[r][band] = sum_p coef[p][r] basis[p][band] against numpy, odd sizes included."""
+@pytest.mark.parametrize("offset", [0, 3])
+@pytest.mark.parametrize("P,B,R", [(12, 2101, 1000), (1, 7, 3), (16, 1024, 129), (5, 1025, 128), (9, 300, 257),
+                                   (3, 2047, 40), (2, 1040, 33), (4, 3071, 17), (6, 33, 50), (7, 2101, 1),
+                                   (12, 2101, 15), (2, 4100, 9)])
+def test_reconstruct_kernel(gpu_lib, P, B, R, precision, offset):
+    """out[r][band] = sum_p coef[p][r] basis[p][band] against numpy: odd row lengths (every
+    128-byte alignment class), lengths next to the workgroup width, rows shorter than a line,
+    fewer rows than classes, and an output pointer that itself starts mid-line (``offset``
+    elements in).  Sentinels before and after the output must survive."""
+    import ctypes
     rs = np.random.RandomState(P + B + R)
     basis = rs.standard_normal((P, B)).astype(precision)
     coef = rs.standard_normal((P, R)).astype(precision)
     ctx = _lib.default_context(0)
     d_b, d_c = ctx.to_device(basis), ctx.to_device(coef)
     pad = 64
-    d_o = ctx.to_device(np.full(R * B + pad, -3.5, precision))
-    ctx.reconstruct_device(precision, d_b, d_c, d_o, R, P, B)
-    out = ctx.to_host(d_o, (R * B + pad,), precision)
+    isz = np.dtype(precision).itemsize
+    d_o = ctx.to_device(np.full(offset + R * B + pad, -3.5, precision))
+    ctx.reconstruct_device(precision, d_b, d_c, ctypes.c_void_p(d_o.value + offset * isz), R, P, B)
+    out = ctx.to_host(d_o, (offset + R * B + pad,), precision)
     for p_ in (d_b, d_c, d_o):
         ctx.free(p_)
-    assert np.all(out[R * B:] == -3.5)
+    assert np.all(out[:offset] == -3.5) and np.all(out[offset + R * B:] == -3.5)
     ref = coef.astype(np.float64).T @ basis.astype(np.float64)
     tol = 1e-13 if precision == np.float64 else 1e-5
-    assert np.max(np.abs(out[:R * B].reshape(R, B) - ref)) / np.max(np.abs(ref)) <= tol
+    assert np.max(np.abs(out[offset:offset + R * B].reshape(R, B) - ref)) / np.max(np.abs(ref)) <= tol
 
 
 # ---------------------------------------------------------------------------------------

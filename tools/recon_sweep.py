@@ -8,7 +8,7 @@ rs = np.random.RandomState(0)
 P = 12
 for dt in (np.float64, np.float32):
     isz = np.dtype(dt).itemsize
-    for B, R in ((2101, 1000000), (2048, 1000000), (2104, 1000000), (1024, 2000000), (2101, 100000)):
+    for B, R in ((2101, 1000000), (2104, 1000000), (2112, 1000000), (2048, 1000000), (2101, 100000)):
         basis = rs.standard_normal((P, B)).astype(dt)
         coef = rs.standard_normal((P, R)).astype(dt)
         d_b, d_c = ctx.to_device(basis), ctx.to_device(coef)
