@@ -19,6 +19,10 @@
 #pragma once
 #include "gp_predict_kernel.hpp"
 
+#ifndef GP_HESS_ABLATE
+#define GP_HESS_ABLATE 0
+#endif
+
 namespace gpk {
 
 template <typename T>
@@ -68,20 +72,35 @@ __device__ __forceinline__ void hessian_pass(const T* s_xa, const T* s_sd, const
 #pragma unroll
   for (int q = 0; q < NP_; ++q) acc[q] = T(0);
   T mu = T(0);
-  // one training point per iteration, NOT unrolled: unrolling lets the scheduler keep
-  // several points' delta vectors live on top of the accumulators and spill
+  // One training point per iteration, NOT unrolled (unrolling lets the scheduler keep several
+  // points' delta vectors live on top of the accumulators and spill).  The NEXT point's row is
+  // read from LDS while this one's products issue, and the squared distance is summed in four
+  // short chains: with two waves per SIMD the loop is otherwise latency-bound (LDS read -> 16
+  // dependent fmas -> exp before the first of the independent products can start).
+  T nxt[D + 1];
+  {
+    const T* row = &s_xa[R::own_sub(0, g) * DS];
+#pragma unroll
+    for (int d = 0; d <= D; ++d) nxt[d] = row[d];
+  }
 #pragma unroll 1
   for (int qq = 0; qq < 4 * nb; ++qq) {
-    const int i = 16 * (qq >> 2) + R::own_sub(qq & 3, g);
-    const T* row = &s_xa[i * DS];
     T dl[D];
-    T r2 = T(0);
+    T r2p[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      dl[d] = row[d] - t[d];
-      r2 = fma(dl[d], dl[d], r2);
+      dl[d] = nxt[d] - t[d];
+      r2p[d & 3] = fma(dl[d], dl[d], r2p[d & 3]);
     }
-    const T w = b * R::exp_(T(-0.5) * r2) * row[D];
+    const T alpha = nxt[D];
+    {   // prefetch (the row after the last is row 0 again: harmless, in range)
+      const int qn = (qq + 1 < 4 * nb) ? qq + 1 : 0;
+      const T* row = &s_xa[(16 * (qn >> 2) + R::own_sub(qn & 3, g)) * DS];
+#pragma unroll
+      for (int d = 0; d <= D; ++d) nxt[d] = row[d];
+    }
+    const T r2 = (r2p[0] + r2p[1]) + (r2p[2] + r2p[3]);
+    const T w = b * R::exp_(T(-0.5) * r2) * alpha;
     mu += w;
     int q = 0;
 #pragma unroll
@@ -94,6 +113,13 @@ __device__ __forceinline__ void hessian_pass(const T* s_xa, const T* s_sd, const
       }
     }
   }
+#if GP_HESS_ABLATE == 2   // diagnostic: no reductions, no stores (one guarded store keeps the sums alive)
+  T keep = mu;
+#pragma unroll
+  for (int q = 0; q < NP_; ++q) keep += acc[q];
+  if (keep == T(-12345.678)) out[0] = keep;
+  return;
+#endif
   mu = xor_reduce_groups(mu);
   int q = 0;
 #pragma unroll
@@ -103,11 +129,15 @@ __device__ __forceinline__ void hessian_pass(const T* s_xa, const T* s_sd, const
       T v = xor_reduce_groups(acc[q]) * (s_sd[d] * s_sd[d2]);
       if (d2 == d) v = fma(-(s_sd[d] * s_sd[d]), mu, v);
       ++q;
+#if GP_HESS_ABLATE == 1   // diagnostic: reductions but no stores
+      if (v == T(-12345.678)) out[0] = v;
+#else
       if (row_ok && d < d_actual && d2 < d_actual) {
         // element (d, d2) by lane group d & 3, its mirror (d2, d) by group d2 & 3
         if ((d & 3) == g) out[d * d_actual + d2] = v;
         if (d2 != d && (d2 & 3) == g) out[d2 * d_actual + d] = v;
       }
+#endif
     }
   }
 }

@@ -250,27 +250,51 @@ struct PredictArgs {
   unsigned long long* dbg;   // GP_STAMPS builds only: [8] segment cycle sums; else unused
 };
 
-// Same for N values at once: all exchanges of a step are issued back to back and waited for
-// together (one LDS-crossbar latency per step instead of one per value).
+// v[l] + v[l ^ 16] (XOR = 16) or v[l] + v[l ^ 32] (XOR = 32) in every lane, with gfx950's
+// v_permlane16_swap / v_permlane32_swap: swapping a register with a copy of itself leaves
+// "every lane holds its own half's value" in one result and "the other half's" in the other.
+// Pure VALU -- no LDS crossbar round trip, no s_waitcnt -- and bit-identical to the __shfl_xor
+// form (a + b == b + a).
+template <int XOR>
+__device__ __forceinline__ unsigned swap_halves(unsigned x, unsigned& other) {
+  if constexpr (XOR == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    other = r[1];
+    return r[0];
+  } else {
+    auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    other = r[1];
+    return r[0];
+  }
+}
+template <int XOR>
+__device__ __forceinline__ float pair_sum(float v) {
+  unsigned o, a = swap_halves<XOR>(__float_as_uint(v), o);
+  return __uint_as_float(a) + __uint_as_float(o);
+}
+template <int XOR>
+__device__ __forceinline__ double pair_sum(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  unsigned lo_o, hi_o;
+  const unsigned lo_a = swap_halves<XOR>((unsigned)u, lo_o);
+  const unsigned hi_a = swap_halves<XOR>((unsigned)(u >> 32), hi_o);
+  const double a = __longlong_as_double((long long)(((unsigned long long)hi_a << 32) | lo_a));
+  const double o = __longlong_as_double((long long)(((unsigned long long)hi_o << 32) | lo_o));
+  return a + o;
+}
+
+// Same for N values at once (kept as an interface: with the swap form there is no latency to
+// batch, the values are simply reduced one after the other).
 template <typename T, int N>
 __device__ inline void xor_reduce_groups_n(T* v) {
-  T o[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) o[i] = __shfl_xor(v[i], 16, 64);
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += o[i];
-#pragma unroll
-  for (int i = 0; i < N; ++i) o[i] = __shfl_xor(v[i], 32, 64);
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += o[i];
+  for (int i = 0; i < N; ++i) v[i] = pair_sum<32>(pair_sum<16>(v[i]));
 }
 
 template <typename T>
 __device__ inline T xor_reduce_groups(T v) {
   // sum over the four 16-lane groups (lanes l, l^16, l^32, l^48)
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  return pair_sum<32>(pair_sum<16>(v));
 }
 
 // One chunk (kChunk fragments of 64 reals) global -> LDS by LDS-DMA
