@@ -33,3 +33,173 @@ def predict_bands(gps, testing, precision=np.float64, device=0):
         return batch.predict(np.asarray(testing))
     finally:
         batch.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# Training many per-band emulators at once
+# ---------------------------------------------------------------------------------------------
+class _GatheredObjective(object):
+    """Turns many concurrent single-theta evaluations into few batched ones.
+
+    Each optimiser thread calls ``evaluate(slot, theta)`` and blocks.  When every thread that
+    is still optimising has a request in, the thread that completed the set runs ONE batched
+    evaluation for all of them (``batch_fn(thetas, targets) -> (cost, grad)``; on the GPU one
+    launch of the likelihood kernels, one workgroup per request) and wakes the others.  No
+    dispatcher thread, no polling; the scipy L-BFGS-B instances stay ordinary and independent.
+    """
+
+    def __init__(self, batch_fn, n_slots, n_train, n_theta):
+        import threading
+        self._fn = batch_fn
+        self._cv = threading.Condition()
+        self._thetas = np.zeros((n_slots, n_theta))
+        self._targets = np.zeros((n_slots, n_train))
+        self._cost = np.zeros(n_slots)
+        self._grad = np.zeros((n_slots, n_theta))
+        self._pending = np.zeros(n_slots, dtype=bool)
+        self._active = n_slots          # threads that may still submit requests
+        self._round = 0
+        self._error = None
+        self.launches = 0
+        self.evaluations = 0
+
+    def set_targets(self, slot, targets):
+        self._targets[slot] = targets
+
+    def _flush_locked(self):
+        idx = np.flatnonzero(self._pending)
+        try:
+            cost, grad = self._fn(self._thetas[idx], self._targets[idx])
+            self._cost[idx] = cost
+            self._grad[idx] = grad
+        except BaseException as exc:          # wake everybody, re-raise in every thread
+            self._error = exc
+        self.launches += 1
+        self.evaluations += idx.size
+        self._pending[idx] = False
+        self._round += 1
+        self._cv.notify_all()
+
+    def evaluate(self, slot, theta):
+        with self._cv:
+            self._thetas[slot] = theta
+            self._pending[slot] = True
+            my_round = self._round
+            if int(self._pending.sum()) >= self._active:
+                self._flush_locked()
+            else:
+                while self._round == my_round and self._error is None:
+                    self._cv.wait()
+            if self._error is not None:
+                raise self._error
+            return float(self._cost[slot]), self._grad[slot].copy()
+
+    def retire(self):
+        """The calling thread will submit no more requests."""
+        with self._cv:
+            self._active -= 1
+            if self._active > 0 and int(self._pending.sum()) >= self._active:
+                self._flush_locked()
+
+
+def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch_fn=None,
+                device=0, verbose=False):
+    """``learn_hyperparameters(n_tries)`` for every GaussianProcess in ``gps`` (per-band
+    emulators on the SAME training inputs, tests/test_perband_emulator.py:22-37), with the
+    optimisations of all bands and all restarts advancing side by side: ``concurrency``
+    scipy L-BFGS-B instances run in threads and their cost/gradient requests are gathered
+    into batched launches of the likelihood kernels (one workgroup per request).
+
+    Starting points are drawn exactly as a loop of ``gp.learn_hyperparameters(n_tries)`` calls
+    would draw them (``5 (rand(n_tries, D+2) - 0.5)`` per emulator, in order, from
+    ``numpy.random``), unless ``starts`` (E, n_tries, D+2) is given.  On return every emulator
+    is set to its best theta (``theta``, ``invQ``, ``invQt``), as the reference leaves it
+    (GaussianProcess.py:183-209).  Returns ``(costs (E,), thetas (E, D+2), stats)``.
+
+    ``batch_fn(thetas, targets) -> (cost, grad)`` replaces the GPU objective (tests use a numpy
+    one); ``is_gpu`` must be true otherwise -- there is no silent CPU path.
+    """
+    import threading
+    import warnings
+    from queue import Queue, Empty
+    from scipy.optimize import fmin_l_bfgs_b
+    if not gps:
+        raise ValueError("need at least one GaussianProcess")
+    inputs = np.ascontiguousarray(gps[0].inputs, dtype=np.float64)
+    for gp in gps[1:]:
+        if np.asarray(gp.inputs).shape != inputs.shape or not np.array_equal(gp.inputs, inputs):
+            raise ValueError("per-band emulators must share the same training inputs")
+    E, (N, D) = len(gps), inputs.shape
+    ctx = None
+    if batch_fn is None:
+        if not is_gpu:
+            raise ValueError("learn_bands runs the objective on the GPU; pass is_gpu=True")
+        ctx = _lib.default_context(device)
+
+        def batch_fn(thetas, targets):
+            return ctx.likelihood_batch(thetas, inputs, targets)
+    if starts is None:
+        starts = np.stack([5. * (np.random.rand(n_tries, D + 2) - 0.5) for _ in range(E)])
+    starts = np.asarray(starts, dtype=np.float64).reshape(E, -1, D + 2)
+    n_tries = starts.shape[1]
+    jobs = Queue()
+    for e in range(E):
+        for k in range(n_tries):
+            jobs.put((e, k))
+    n_threads = int(max(1, min(concurrency, E * n_tries)))
+    gather = _GatheredObjective(batch_fn, n_threads, N, D + 2)
+    best_cost = np.full((E, n_tries), np.inf)
+    best_theta = np.zeros((E, n_tries, D + 2))
+    failures = []
+
+    def worker(slot):
+        try:
+            while True:
+                try:
+                    e, k = jobs.get_nowait()
+                except Empty:
+                    return
+                gather.set_targets(slot, np.asarray(gps[e].targets, dtype=np.float64))
+                try:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        th, f, _ = fmin_l_bfgs_b(lambda t: gather.evaluate(slot, t), starts[e, k],
+                                                 factr=0.1, pgtol=1e-20, iprint=-1)
+                    best_cost[e, k], best_theta[e, k] = f, th
+                except np.linalg.LinAlgError:      # reference :176-181: keep going, cost 9999
+                    best_cost[e, k], best_theta[e, k] = 9999.0, starts[e, k]
+        except BaseException as exc:
+            failures.append(exc)
+        finally:
+            gather.retire()
+
+    threads = [threading.Thread(target=worker, args=(s,), daemon=True) for s in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if failures:
+        raise failures[0]
+    pick = np.argmin(best_cost, axis=1)
+    costs = best_cost[np.arange(E), pick]
+    thetas = best_theta[np.arange(E), pick]
+    # leave every emulator set to its optimum: invQ / invQt for all bands, a few launches
+    if ctx is not None:
+        step = 128
+        for s in range(0, E, step):
+            sl = slice(s, min(E, s + step))
+            tg = np.stack([np.asarray(gp.targets, dtype=np.float64) for gp in gps[sl]])
+            c, g, invQ, invQt = ctx.likelihood_batch(thetas[sl], inputs, tg, want_inverse=True)
+            for i, gp in enumerate(gps[sl]):
+                gp.theta = thetas[s + i].copy()
+                gp.invQ, gp.invQt = invQ[i].copy(), invQt[i].copy()
+                gp.current_theta, gp.current_loglikelihood = gp.theta, float(c[i])
+                gp._gpu_models = {}
+    else:
+        for e, gp in enumerate(gps):
+            gp._set_params(thetas[e].copy())
+    stats = {"launches": gather.launches, "evaluations": gather.evaluations, "threads": n_threads}
+    if verbose:
+        print("learn_bands: %d emulators x %d starts, %d evaluations in %d launches" % (
+            E, n_tries, gather.evaluations, gather.launches))
+    return costs, thetas, stats

@@ -628,3 +628,29 @@ def test_multivariate_set_up_on_gpu_and_storage(gpu_lib, tmp_path):
     assert np.max(np.abs(back.predict_many(Y, is_gpu=True) - f_dev)) <= 1e-12 * np.max(np.abs(f_dev))
     one, jac = back.predict(Y[0], is_gpu=True)
     assert np.max(np.abs(one - f_dev[0])) <= 1e-10 * np.max(np.abs(f_dev[0]))
+
+
+def test_learn_bands_on_gpu_matches_sequential(gpu_lib):
+    """perband.learn_bands: all bands x restarts advance together, their objective requests
+    gathered into batched launches; same optima as gp.learn_hyperparameters band by band."""
+    import warnings
+    from gp_emulator_amd import perband
+    g = load_golden("training_objective")
+    X = g["smooth_inputs"]
+    rs = np.random.RandomState(3)
+    bands = [g["smooth_targets"] * (1 + 0.1 * e) + 0.05 * rs.standard_normal(120) for e in range(6)]
+    gps = [GaussianProcess(X, t) for t in bands]
+    np.random.seed(21)
+    costs, thetas, stats = perband.learn_bands(gps, n_tries=2, concurrency=12)
+    assert stats["threads"] == 12 and stats["evaluations"] / stats["launches"] > 4
+    np.random.seed(21)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for e, t in enumerate(bands):
+            ref = GaussianProcess(X, t)
+            c, th = ref.learn_hyperparameters(n_tries=2)          # numpy branch, same starts
+            assert abs(c - costs[e]) <= 1e-5 * max(1.0, abs(c)), (e, c, costs[e])
+    mu, var, der = perband.predict_bands(gps, X[:40])
+    for e, gp in enumerate(gps):
+        ref = gp_oracle.cpu_predict(X, gp.theta, gp.invQ, gp.invQt, X[:40])
+        assert gp_oracle.maxnorm_err(ref[0], mu[e]) <= 1e-10

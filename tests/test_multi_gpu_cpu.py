@@ -94,3 +94,73 @@ def test_gloo_world2_barrier_and_max_timing(tmp_path):
     assert out["world"] == 2
     assert out["rows"] == 2 * 5 * 2000                 # whole-job units over all ranks
     assert out["dt"] >= 5 * 0.02                       # max over ranks: the slow rank's time
+
+
+# ---------------------------------------------------------------------------------------------
+# perband.learn_bands: the request-gathering runtime, driven by a numpy objective (no GPU)
+# ---------------------------------------------------------------------------------------------
+def _bands_problem(n_bands=5, n=30, d=2, seed=0):
+    rs = np.random.RandomState(seed)
+    X = rs.random_sample((n, d))
+    bands = [np.sin(X.sum(1) * (1 + 0.3 * e)) + 0.05 * rs.standard_normal(n) for e in range(n_bands)]
+    return X, bands
+
+
+def _numpy_objective(X, calls):
+    from oracle import gp_oracle
+
+    def fn(thetas, targets):
+        calls.append(len(thetas))
+        c = np.array([gp_oracle.loglikelihood(X, tg, th) for th, tg in zip(thetas, targets)])
+        g = np.stack([gp_oracle.partial_devs(X, tg, th) for th, tg in zip(thetas, targets)])
+        return c, g
+    return fn
+
+
+def test_learn_bands_matches_a_loop_of_learn_hyperparameters():
+    """Same starting points (drawn in the same order from numpy.random), same optimiser, batched
+    objective: every band ends at the optimum the reference-style loop finds, and the requests
+    really were gathered (several per call of the objective)."""
+    import warnings
+    from gp_emulator_amd import GaussianProcess, perband
+    X, bands = _bands_problem()
+    gps = [GaussianProcess(X, t) for t in bands]
+    calls = []
+    np.random.seed(11)
+    costs, thetas, stats = perband.learn_bands(gps, n_tries=2, concurrency=4,
+                                               batch_fn=_numpy_objective(X, calls))
+    assert stats["threads"] == 4 and stats["evaluations"] == sum(calls) and stats["launches"] == len(calls)
+    assert max(calls) == 4 and sum(calls) / len(calls) > 2.0
+    np.random.seed(11)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for e, t in enumerate(bands):
+            ref = GaussianProcess(X, t)
+            c, th = ref.learn_hyperparameters(n_tries=2)
+            assert abs(c - costs[e]) <= 1e-6 * max(1.0, abs(c))
+            # the emulator is left set to its optimum, ready to predict
+            assert np.allclose(gps[e].theta, thetas[e]) and gps[e].invQ.shape == (30, 30)
+            assert np.allclose(gps[e].predict(X[:5])[0], ref.predict(X[:5])[0], atol=1e-5)
+
+
+def test_learn_bands_edge_cases():
+    from gp_emulator_amd import GaussianProcess, perband
+    X, bands = _bands_problem(n_bands=3)
+    gps = [GaussianProcess(X, t) for t in bands]
+    with pytest.raises(ValueError):
+        perband.learn_bands([], batch_fn=lambda a, b: None)
+    with pytest.raises(ValueError):
+        perband.learn_bands(gps, is_gpu=False)                       # no silent CPU path
+    with pytest.raises(ValueError):
+        perband.learn_bands(gps + [GaussianProcess(X + 1.0, bands[0])], batch_fn=lambda a, b: None)
+
+    def broken(thetas, targets):
+        raise RuntimeError("objective failed")
+    with pytest.raises(RuntimeError):                                 # every thread is released
+        perband.learn_bands(gps, n_tries=2, concurrency=3, batch_fn=broken)
+    # more threads than problems, explicit starts, one try
+    calls = []
+    starts = np.zeros((3, 1, 4))
+    costs, thetas, stats = perband.learn_bands(gps, concurrency=64, starts=starts,
+                                               batch_fn=_numpy_objective(X, calls))
+    assert stats["threads"] == 3 and costs.shape == (3,) and thetas.shape == (3, 4)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-band training at scale (tests/test_perband_emulator.py:22-37 for many bands): K band-mean
+emulators on the PROSAIL training inputs (N=250, D=10), n_tries restarts each, trained together by
+perband.learn_bands; a few of them also one by one with gp.learn_hyperparameters(is_gpu=True) for
+the per-band time of the unbatched GPU route.
+
+    python tools/learn_bands_timing.py [--bands 64] [--tries 5] [--concurrency 256] [--single 4]
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gp_emulator_amd import GaussianProcess, perband  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bands", type=int, default=64)
+ap.add_argument("--tries", type=int, default=5)
+ap.add_argument("--concurrency", type=int, default=256)
+ap.add_argument("--single", type=int, default=4)
+a = ap.parse_args()
+with np.load(os.path.join(ROOT, "tests", "golden", "prosail_mv.npz"), allow_pickle=False) as f:
+    X_train, y_train = f["train_data"].T @ f["basis_functions"], f["y_train"]
+width = 34                                         # the reference's band pass is 34 columns wide
+cols = np.linspace(0, X_train.shape[1] - width, a.bands).astype(int)
+targets = [X_train[:, c:c + width].mean(axis=1) for c in cols]
+gps = [GaussianProcess(y_train * 1, t) for t in targets]
+warnings.simplefilter("ignore")
+np.random.seed(5)
+t0 = time.time()
+costs, thetas, stats = perband.learn_bands(gps, n_tries=a.tries, concurrency=a.concurrency)
+dt = time.time() - t0
+print("learn_bands: %d bands x %d starts in %.2f s (%.3f s per band); %d evaluations in %d launches "
+      "(%.1f per launch), %d optimiser threads" % (a.bands, a.tries, dt, dt / a.bands, stats["evaluations"],
+                                                    stats["launches"], stats["evaluations"] / stats["launches"],
+                                                    stats["threads"]))
+np.random.seed(5)
+t0 = time.time()
+worst = 0.0
+for e in range(min(a.single, a.bands)):
+    gp = GaussianProcess(y_train * 1, targets[e])
+    c, th = gp.learn_hyperparameters(n_tries=a.tries, is_gpu=True)
+    worst = max(worst, abs(c - costs[e]) / max(1.0, abs(c)))
+dt1 = (time.time() - t0) / max(1, min(a.single, a.bands))
+print("one band at a time, learn_hyperparameters(is_gpu=True): %.2f s per band; largest relative cost "
+      "difference to learn_bands over those bands %.1e" % (dt1, worst))
