@@ -98,6 +98,10 @@ class GaussianProcess:
             ctx = _lib.default_context(0)
             cost, grad, invQ, invQt = ctx.likelihood_batch(theta[None, :], self.inputs,
                                                            self.targets, want_inverse=True)
+            if not np.isfinite(cost[0]):
+                # a pivot of the elimination was <= 0: what numpy's Cholesky reports as
+                # LinAlgError on the reference's path (:66, caught in _learn, :176-181)
+                raise np.linalg.LinAlgError("Matrix is not positive definite")
             self.theta = theta
             self.invQ, self.invQt = invQ[0], invQt[0]
             self._gpu_models = {}

@@ -82,6 +82,12 @@ class MultivariateEmulator(object):
         for i in range(self.n_pcs):
             self.emulators.append(GaussianProcess(np.atleast_2d(y), train_data[i]))
         if hyperparams is None:
+            if is_gpu and self.n_pcs > 1:
+                # all PCs and restarts together (same starting points as the loop below would draw)
+                from . import perband
+                costs, thetas, _ = perband.learn_bands(self.emulators, n_tries=n_tries)
+                self.hyperparams[:, :] = thetas.T
+                return
             for i, gp in enumerate(self.emulators):
                 self.hyperparams[:, i] = gp.learn_hyperparameters(n_tries=n_tries, is_gpu=is_gpu)[1]
             return

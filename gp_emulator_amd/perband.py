@@ -102,6 +102,14 @@ class _GatheredObjective(object):
                 self._flush_locked()
 
 
+def _finite(cost_grad):
+    """A non-finite cost means a pivot of the elimination was <= 0 -- what the reference's numpy
+    path reports as LinAlgError (GaussianProcess.py:66) and its optimiser loop catches (:176-181)."""
+    if not np.isfinite(cost_grad[0]):
+        raise np.linalg.LinAlgError("Matrix is not positive definite")
+    return cost_grad
+
+
 def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch_fn=None,
                 device=0, verbose=False):
     """``learn_hyperparameters(n_tries)`` for every GaussianProcess in ``gps`` (per-band
@@ -163,8 +171,8 @@ def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch
                 try:
                     with warnings.catch_warnings():
                         warnings.simplefilter("ignore")
-                        th, f, _ = fmin_l_bfgs_b(lambda t: gather.evaluate(slot, t), starts[e, k],
-                                                 factr=0.1, pgtol=1e-20, iprint=-1)
+                        th, f, _ = fmin_l_bfgs_b(lambda t: _finite(gather.evaluate(slot, t)),
+                                                 starts[e, k], factr=0.1, pgtol=1e-20, iprint=-1)
                     best_cost[e, k], best_theta[e, k] = f, th
                 except np.linalg.LinAlgError:      # reference :176-181: keep going, cost 9999
                     best_cost[e, k], best_theta[e, k] = 9999.0, starts[e, k]

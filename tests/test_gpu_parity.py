@@ -654,3 +654,40 @@ def test_learn_bands_on_gpu_matches_sequential(gpu_lib):
     for e, gp in enumerate(gps):
         ref = gp_oracle.cpu_predict(X, gp.theta, gp.invQ, gp.invQt, X[:40])
         assert gp_oracle.maxnorm_err(ref[0], mu[e]) <= 1e-10
+
+
+def test_multivariate_emulator_trains_on_gpu(gpu_lib):
+    """MultivariateEmulator(X, y, is_gpu=True) without hyperparams: every PC's GP is trained
+    (reference multivariate_gp.py:180-184), all of them together through perband.learn_bands;
+    same hyper-parameters' costs as the numpy loop from the same seed."""
+    import warnings
+    from gp_emulator_amd import MultivariateEmulator
+    rs = np.random.RandomState(4)
+    y = rs.random_sample((40, 2))
+    w = np.linspace(0, 1, 12)
+    X = (np.outer(np.sin(3 * y[:, 0]), np.cos(2 * w)) + np.outer(y[:, 1] ** 2, w) +
+         np.outer(np.cos(2 * y.sum(1)), np.sin(3 * w)) + 0.01 * rs.standard_normal((40, 12)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(0)
+        dev = MultivariateEmulator(X=X, y=y, thresh=0.98, n_tries=2, is_gpu=True)
+        np.random.seed(0)
+        host = MultivariateEmulator(X=X, y=y, thresh=0.98, n_tries=2)
+    assert dev.n_pcs == host.n_pcs >= 2
+    for a, b in zip(dev.emulators, host.emulators):
+        assert abs(a.current_loglikelihood - b.current_loglikelihood) <= 1e-5 * max(1.0, abs(b.current_loglikelihood))
+    f_dev = dev.predict_many(y[:8], is_gpu=True)
+    assert np.max(np.abs(f_dev - host.predict_many(y[:8], is_gpu=False))) <= 1e-4 * np.max(np.abs(f_dev))
+
+
+def test_gpu_objective_reports_a_non_positive_definite_matrix(gpu_lib):
+    """Duplicate training points and no noise: Q is singular.  The reference's numpy path raises
+    LinAlgError from its Cholesky (GaussianProcess.py:66); the GPU objective does the same (its
+    pivots give a non-finite cost), so _learn's handler (:176-181) keeps working."""
+    X = np.repeat(np.random.RandomState(0).random_sample((10, 2)), 2, axis=0)
+    gp = GaussianProcess(X, np.sin(X.sum(1)))
+    theta = np.array([0.0, 0.0, 0.0, -800.0])
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.loglikelihood(theta, is_gpu=True)
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.loglikelihood(theta, is_gpu=False)
