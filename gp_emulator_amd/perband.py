@@ -46,19 +46,26 @@ class _GatheredObjective(object):
     evaluation for all of them (``batch_fn(thetas, targets) -> (cost, grad)``; on the GPU one
     launch of the likelihood kernels, one workgroup per request) and wakes the others.  No
     dispatcher thread, no polling; the scipy L-BFGS-B instances stay ordinary and independent.
+
+    Synchronisation is deliberately primitive: one short critical section to register a request,
+    and one private lock per thread to sleep on (released by whoever ran the batch).  A shared
+    ``Condition`` + ``notify_all`` makes every woken thread queue for the same lock again and,
+    with a few hundred threads, costs several times more than the evaluations themselves.
     """
 
     def __init__(self, batch_fn, n_slots, n_train, n_theta):
         import threading
         self._fn = batch_fn
-        self._cv = threading.Condition()
+        self._lock = threading.Lock()
+        self._wake = [threading.Lock() for _ in range(n_slots)]
+        for w in self._wake:
+            w.acquire()                 # held: a waiter blocks until the batch runner releases it
         self._thetas = np.zeros((n_slots, n_theta))
         self._targets = np.zeros((n_slots, n_train))
         self._cost = np.zeros(n_slots)
         self._grad = np.zeros((n_slots, n_theta))
-        self._pending = np.zeros(n_slots, dtype=bool)
+        self._waiting = []              # slots with a request in
         self._active = n_slots          # threads that may still submit requests
-        self._round = 0
         self._error = None
         self.launches = 0
         self.evaluations = 0
@@ -66,40 +73,45 @@ class _GatheredObjective(object):
     def set_targets(self, slot, targets):
         self._targets[slot] = targets
 
-    def _flush_locked(self):
-        idx = np.flatnonzero(self._pending)
+    def _run(self, batch, me):
+        # every live thread is in `batch` and asleep (or is `me`): nothing else touches the state
+        idx = np.array(batch)
         try:
             cost, grad = self._fn(self._thetas[idx], self._targets[idx])
             self._cost[idx] = cost
             self._grad[idx] = grad
-        except BaseException as exc:          # wake everybody, re-raise in every thread
+        except BaseException as exc:    # wake everybody, re-raise in every thread
             self._error = exc
         self.launches += 1
-        self.evaluations += idx.size
-        self._pending[idx] = False
-        self._round += 1
-        self._cv.notify_all()
+        self.evaluations += len(batch)
+        for s in batch:
+            if s != me:
+                self._wake[s].release()
 
     def evaluate(self, slot, theta):
-        with self._cv:
-            self._thetas[slot] = theta
-            self._pending[slot] = True
-            my_round = self._round
-            if int(self._pending.sum()) >= self._active:
-                self._flush_locked()
-            else:
-                while self._round == my_round and self._error is None:
-                    self._cv.wait()
-            if self._error is not None:
-                raise self._error
-            return float(self._cost[slot]), self._grad[slot].copy()
+        self._thetas[slot] = theta
+        with self._lock:
+            self._waiting.append(slot)
+            batch = None
+            if len(self._waiting) >= self._active:
+                batch, self._waiting = self._waiting, []
+        if batch is not None:
+            self._run(batch, slot)
+        else:
+            self._wake[slot].acquire()
+        if self._error is not None:
+            raise self._error
+        return float(self._cost[slot]), self._grad[slot].copy()
 
     def retire(self):
         """The calling thread will submit no more requests."""
-        with self._cv:
+        with self._lock:
             self._active -= 1
-            if self._active > 0 and int(self._pending.sum()) >= self._active:
-                self._flush_locked()
+            batch = None
+            if self._active > 0 and len(self._waiting) >= self._active:
+                batch, self._waiting = self._waiting, []
+        if batch is not None:
+            self._run(batch, -1)
 
 
 def _finite(cost_grad):
