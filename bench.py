@@ -360,6 +360,16 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what the kernel really executes on the dominant pipe (not the algorithmic count above):
+        # folded variance = 4 NB(NB+1)/2 MFMAs of 16x16x4 per 16-row tile; Hessian = D(D+1)/2 fmas
+        # per (training point, test point) over the padded training set
+        nb_pad = model.info()["kernel_nb"] if kind != "hessian" else (N + 15) // 16
+        if kind == "hessian":
+            kd = model.info()["kernel_d"]
+            exec_flop_pt = 2 * 16 * nb_pad * kd * (kd + 1) // 2
+        else:
+            exec_flop_pt = 4 * nb_pad * (nb_pad + 1) // 2 * 2048 // 16
+        executed_tf = exec_flop_pt * units / kern_avg_s / 1e12
         kname = {"predict": "predict_kernel", "batch": "predict_kernel", "hessian": "hessian_kernel"}[kind]
         ctype = "double" if a.precision == "f64" else "float"
         minfo = model.info()
@@ -388,6 +398,11 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic,
                          "kernel": kfull, "kernel_ms": kern_avg_s * 1e3,
                          "flop_per_point": flop_pt,
+                         "executed": {"flop_per_point": exec_flop_pt, "achieved": executed_tf,
+                                      "frac": executed_tf / peak,
+                                      "what": ("variance MFMAs actually issued (symmetric folding)"
+                                               if kind != "hessian" else
+                                               "pair-product fmas actually issued (upper triangle)")},
                          "note": ("achieved = algorithmic flop/pt of SURVEY.md 8d (un-halved variance "
                                   "contraction / Hessian as the reference writes it) x units per launch "
                                   "/ HIP-event kernel time.  The kernel EXECUTES fewer flops than that "
