@@ -364,7 +364,13 @@ def main():
         # folded variance = 4 NB(NB+1)/2 MFMAs of 16x16x4 per 16-row tile; Hessian = D(D+1)/2 fmas
         # per (training point, test point) over the padded training set
         nb_pad = model.info()["kernel_nb"] if kind != "hessian" else (N + 15) // 16
-        if kind == "hessian":
+        hess_mfma = (kind == "hessian" and model.info()["kernel_d"] in (10, 11, 12, 16)
+                     and model.info()["kernel_nb"] > 0 and not int(os.environ.get("GP_HESS_VALU", "0")))
+        if hess_mfma:
+            # 4 x 4 blocks (bi <= bj) of the D x D matrix, 4 NB MFMAs of 16x16x4 each per 16-row tile
+            nb4 = (model.info()["kernel_d"] + 3) // 4
+            exec_flop_pt = nb4 * (nb4 + 1) // 2 * 4 * model.info()["kernel_nb"] * 2048 // 16
+        elif kind == "hessian":
             kd = model.info()["kernel_d"]
             exec_flop_pt = 2 * 16 * nb_pad * kd * (kd + 1) // 2
         else:
@@ -373,8 +379,10 @@ def main():
         kname = {"predict": "predict_kernel", "batch": "predict_kernel", "hessian": "hessian_kernel"}[kind]
         ctype = "double" if a.precision == "f64" else "float"
         minfo = model.info()
+        if hess_mfma:
+            kname = "hessian_mfma_kernel"
         kfull = ("%s<%s,%d,%d>" % (kname, ctype, minfo["kernel_d"], minfo["kernel_nb"])
-                 if kind != "hessian" else "%s<%s,%d>" % (kname, ctype, minfo["kernel_d"]))
+                 if kind != "hessian" or hess_mfma else "%s<%s,%d>" % (kname, ctype, minfo["kernel_d"]))
         metric = ("test-points/sec for predict(mean+var+grad), N_train=%d D=%d" % (N, D)
                   if kind != "hessian" else
                   "test-points/sec for hessian (full DxD), N_train=%d D=%d" % (N, D))
@@ -402,7 +410,8 @@ def main():
                                       "frac": executed_tf / peak,
                                       "what": ("variance MFMAs actually issued (symmetric folding)"
                                                if kind != "hessian" else
-                                               "pair-product fmas actually issued (upper triangle)")},
+                                               "pair-product MFMAs actually issued (4 x 4 blocks)" if hess_mfma
+                                               else "pair-product fmas actually issued (upper triangle)")},
                          "note": ("achieved = algorithmic flop/pt of SURVEY.md 8d (un-halved variance "
                                   "contraction / Hessian as the reference writes it) x units per launch "
                                   "/ HIP-event kernel time.  The kernel EXECUTES fewer flops than that "

@@ -82,6 +82,10 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
             tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
                                             "-DGP_NB=%d" % nb, "-c",
                                             os.path.join(CSRC, "gp_kernels_tu.hip"), "-o", obj])
+            obj = os.path.join(OBJ, "hessm_%s_%d.o" % (tname, nb))
+            tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
+                                            "-DGP_NB=%d" % nb, "-c",
+                                            os.path.join(CSRC, "gp_hessian_mfma_tu.hip"), "-o", obj])
         obj = os.path.join(OBJ, "generic_%s.o" % tname)
         tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
                                         os.path.join(CSRC, "gp_generic_tu.hip"), "-o", obj])

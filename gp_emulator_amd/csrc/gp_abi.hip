@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "gp_dispatch.hpp"
 #include "gp_generic_kernel.hpp"
 #include "gp_hessian_kernel.hpp"
+#include "gp_hessian_mfma_kernel.hpp"
 #include "gp_predict_kernel.hpp"
 #include "gp_reconstruct_kernel.hpp"
 #include "gp_train_args.hpp"
@@ -26,6 +28,11 @@ hipError_t launch_reconstruct_f32(const ReconArgs<float>&, int wide, int cus, hi
 hipError_t launch_reconstruct_f64(const ReconArgs<double>&, int wide, int cus, hipStream_t);
 hipError_t launch_generic_f32(const GenericArgs<float>&, int, hipStream_t);
 hipError_t launch_generic_f64(const GenericArgs<double>&, int, hipStream_t);
+#define GP_DECL(nb)                                                                          \
+  hipError_t launch_hessm_f32_##nb(int, const HessMfmaArgs<float>&, int, hipStream_t);      \
+  hipError_t launch_hessm_f64_##nb(int, const HessMfmaArgs<double>&, int, hipStream_t);
+GP_FOR_EACH_KERNEL_NB(GP_DECL)
+#undef GP_DECL
 hipError_t launch_hessian_f32(int, const HessianArgs<float>&, int, hipStream_t);
 hipError_t launch_hessian_f64(int, const HessianArgs<double>&, int, hipStream_t);
 #define GP_DECL(nb)                                                                         \
@@ -83,6 +90,12 @@ struct gp_model {
   void* d_xa;
   void* d_frags;
   void* d_sd;
+  // Hessian on the matrix core (gp_hessian_mfma_kernel.hpp): the constant products
+  // x''_id x''_id2 in fragment order, built on the first Hessian call from a host copy of the
+  // scaled rows (double, [n_train][kernel_d])
+  std::vector<double> xs_host;
+  std::mutex h_mutex;
+  void* d_pfrags;
 };
 
 struct gp_event {
@@ -373,6 +386,7 @@ static int model_create(gp_ctx* ctx, int E, const TH* expX, const TH* inputs, co
   m->frags_stride = fr_len;
   m->sd_stride = sd_len;
   m->d_xa = m->d_frags = m->d_sd = nullptr;
+  m->d_pfrags = nullptr;
   hipError_t e = hipMalloc(&m->d_xa, sizeof(T) * xa_len * E);
   if (e == hipSuccess && invQ) e = hipMalloc(&m->d_frags, sizeof(T) * fr_len * E);
   if (e == hipSuccess) e = hipMalloc(&m->d_sd, sizeof(T) * sd_len * E);
@@ -384,6 +398,12 @@ static int model_create(gp_ctx* ctx, int E, const TH* expX, const TH* inputs, co
                        invQ ? invQ + (size_t)k * N * N : nullptr, N, D, theta_size,
                        xa.data(), invQ ? fr.data() : nullptr, sd.data(), &b);
     if (rc) break;
+    if (E == 1 && knb > 0) {   // the rounded x'' the kernels see, for the Hessian's product matrix
+      const int DSk = row_stride_of(kd);
+      m->xs_host.resize((size_t)N * kd);
+      for (int i = 0; i < N; ++i)
+        for (int d = 0; d < kd; ++d) m->xs_host[(size_t)i * kd + d] = (double)xa[(size_t)i * DSk + d];
+    }
     e = hipMemcpyAsync((T*)m->d_xa + (size_t)k * xa_len, xa.data(), sizeof(T) * xa_len, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && invQ)
       e = hipMemcpyAsync((T*)m->d_frags + (size_t)k * fr_len, fr.data(), sizeof(T) * fr_len, hipMemcpyHostToDevice, ctx->stream);
@@ -482,7 +502,91 @@ hipError_t launch_hessian<double>(int kd, const gpk::HessianArgs<double>& a, int
 }
 
 template <typename T>
+static hipError_t launch_hessm(int knb, int kd, const gpk::HessMfmaArgs<T>& a, int grid, hipStream_t s);
+template <>
+hipError_t launch_hessm<float>(int knb, int kd, const gpk::HessMfmaArgs<float>& a, int grid, hipStream_t s) {
+  switch (knb) {
+#define GP_CASE(nb) case nb: return gpk::launch_hessm_f32_##nb(kd, a, grid, s);
+    GP_FOR_EACH_KERNEL_NB(GP_CASE)
+#undef GP_CASE
+  }
+  return hipErrorInvalidValue;
+}
+template <>
+hipError_t launch_hessm<double>(int knb, int kd, const gpk::HessMfmaArgs<double>& a, int grid, hipStream_t s) {
+  switch (knb) {
+#define GP_CASE(nb) case nb: return gpk::launch_hessm_f64_##nb(kd, a, grid, s);
+    GP_FOR_EACH_KERNEL_NB(GP_CASE)
+#undef GP_CASE
+  }
+  return hipErrorInvalidValue;
+}
+
+static bool hessian_on_matrix_core(const gp_model* m) {
+  if (m->kernel_nb <= 0 || m->n_emulators != 1 || m->xs_host.empty()) return false;
+  if (const char* ev = getenv("GP_HESS_VALU"))      // A/B switch: force the VALU kernel
+    if (atoi(ev) != 0) return false;
+  return m->kernel_d == 10 || m->kernel_d == 11 || m->kernel_d == 12 || m->kernel_d == 16;
+}
+
+// The constant operand of hessian_mfma_kernel, built once per model: P[i][(d, d2)] =
+// x''_id x''_id2 (double product of the rounded coordinates, rounded once to T) in 4 x 4 blocks
+// of (d, d2); fragment (block c, training block I, k-step s) lane l = the product for training
+// point 16 I + own(s, l >> 4) and the block's element that MFMA output row (l & 15) stands for.
+template <typename T>
+static int ensure_hess_frags(gp_ctx* ctx, gp_model* m) {
+  std::lock_guard<std::mutex> lock(m->h_mutex);
+  if (m->d_pfrags) return GP_OK;
+  const int kd = m->kernel_d, knb = m->kernel_nb, N = m->n_train;
+  const size_t n = (size_t)gpk::hess_frag_count_padded(kd, knb, gpk::Geo<T>::kChunk) * 64;
+  std::vector<T> fr(n, T(0));
+  for (int c = 0; c < gpk::hess_blocks(kd); ++c)
+    for (int I = 0; I < knb; ++I)
+      for (int s = 0; s < 4; ++s) {
+        T* f = fr.data() + (size_t)gpk::hess_frag_index(c, I, s, knb) * 64;
+        for (int l = 0; l < 64; ++l) {
+          const int i = gpk::own_index<T>(I, s, l >> 4);
+          const int q = l & 15;             // MFMA output row = accumulator r of lane group g
+          const int d = 4 * gpk::hess_block_bi(c) + gpk::hess_row_r<T>(q);
+          const int d2 = 4 * gpk::hess_block_bj(c) + gpk::hess_row_g<T>(q);
+          if (i >= N || d >= kd || d2 >= kd) continue;
+          f[l] = (T)(m->xs_host[(size_t)i * kd + d] * m->xs_host[(size_t)i * kd + d2]);
+        }
+      }
+  void* dp = nullptr;
+  HIP_TRY(hipMalloc(&dp, sizeof(T) * n));
+  hipError_t e = hipMemcpy(dp, fr.data(), sizeof(T) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(dp);
+    return fail(GP_ERR_HIP, "hessian operand upload: %s", hipGetErrorString(e));
+  }
+  m->d_pfrags = dp;
+  return GP_OK;
+}
+
+template <typename T>
 static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_hess, int64_t M) {
+  if (m->n_inputs > GP_MAX_KERNEL_D)
+    return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
+  if (hessian_on_matrix_core(m)) {
+    int rc = ensure_hess_frags<T>(ctx, const_cast<gp_model*>(m));
+    if (rc) return rc;
+    gpk::HessMfmaArgs<T> h;
+    h.xa = (const T*)m->d_xa;
+    h.pfrags = (const T*)m->d_pfrags;
+    h.sd = (const T*)m->d_sd;
+    h.testing = (const T*)d_testing;
+    h.hess = (T*)d_hess;
+    h.M = M;
+    h.d_actual = m->n_inputs;
+    constexpr int kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
+    const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG;
+    int64_t grid = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU;
+    if (grid > groups) grid = groups;
+    hipError_t e = launch_hessm<T>(m->kernel_nb, m->kernel_d, h, (int)grid, ctx->stream);
+    if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian kernel launch: %s", hipGetErrorString(e));
+    return GP_OK;
+  }
   gpk::HessianArgs<T> a;
   a.xa = (const T*)m->d_xa;
   a.sd = (const T*)m->d_sd;
@@ -491,8 +595,6 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.M = M;
   a.d_actual = m->n_inputs;
   a.nb = (m->n_train + 15) / 16;     // the loop over training points is a run-time loop
-  if (m->n_inputs > GP_MAX_KERNEL_D)
-    return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
   if (sizeof(T) * (16 * (size_t)a.nb * gpk::row_stride(m->kernel_d) + 2 * m->kernel_d) > 160 * 1024)
     return fail(GP_ERR_UNSUPPORTED, "training set too large for the hessian kernel's LDS image");
   const int64_t groups = (M + gpk::hkRowsPerWG - 1) / gpk::hkRowsPerWG;
@@ -772,6 +874,7 @@ int gp_model_destroy(gp_model* m) {
   if (m->d_xa) (void)hipFree(m->d_xa);
   if (m->d_frags) (void)hipFree(m->d_frags);
   if (m->d_sd) (void)hipFree(m->d_sd);
+  if (m->d_pfrags) (void)hipFree(m->d_pfrags);
   delete m;
   return GP_OK;
 }

@@ -6,10 +6,11 @@
 //
 //   hess[d][d2] = sd_d sd_d2 * sum_i w_i delta_id delta_id2  -  [d == d2] e_d * sum_i w_i
 //
-// i.e. a symmetric rank-N update per test row.  It is done on the VALU, not the matrix
-// core: fp64 MFMA and fp64 VALU issue at the same rate on MI355X (and share the pipe --
-// tools/mfma_f64_probe.hip), and only the VALU form can exploit the symmetry (D(D+1)/2
-// products instead of the 16x16 a matrix-core tile would spend), so it is ~2x cheaper.
+// i.e. a symmetric rank-N update per test row, done here on the VALU with D(D+1)/2 fmas per
+// (training point, test row).  This is the kernel for n_inputs < 10; from kernel D = 10 up the
+// same quantity is computed on the matrix core by gp_hessian_mfma_kernel.hpp (the pair products
+// x''_id x''_id2 do not depend on the test row, which turns the sum into a matrix product), which
+// is 1.4x faster at D = 16.  GP_HESS_VALU=1 in the environment forces this kernel for every D.
 //
 // Lane layout as in the predict kernel: lane l works for test row (l & 15) and the quarter
 // (l >> 4) of the training points; the D(D+1)/2 partial sums live in registers (one wave

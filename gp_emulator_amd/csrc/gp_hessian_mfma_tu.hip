@@ -1,0 +1,28 @@
+// One translation unit per (compute dtype, NB): hessian_mfma_kernel<T, D, NB> for the kernel
+// dimensions where the matrix-core form beats the VALU one (D >= 10).  Compiled by build.py with
+// -DGP_T=<float|double> -DGP_TNAME=<f32|f64> -DGP_NB=<blocks of 16 training points>.
+#include "gp_hessian_mfma_kernel.hpp"
+
+#define GP_CAT2(a, b, c) a##b##_##c
+#define GP_CAT(a, b, c) GP_CAT2(a, b, c)
+
+namespace gpk {
+
+template <int D>
+static hipError_t launch_one(const HessMfmaArgs<GP_T>& a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((hessian_mfma_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(Geo<GP_T>::kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t GP_CAT(launch_hessm_, GP_TNAME, GP_NB)(int kernel_d, const HessMfmaArgs<GP_T>& a,
+                                                 int grid, hipStream_t stream) {
+  switch (kernel_d) {
+    case 10: return launch_one<10>(a, grid, stream);
+    case 11: return launch_one<11>(a, grid, stream);
+    case 12: return launch_one<12>(a, grid, stream);
+    case 16: return launch_one<16>(a, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace gpk

@@ -198,6 +198,31 @@ def test_hessian_matches_golden(gpu_lib, name, precision):
     assert np.array_equal(h, np.transpose(h, (0, 2, 1)))      # exactly symmetric by construction
 
 
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("n,d", [(100, 12), (40, 9), (320, 16), (33, 13), (250, 10), (64, 14), (17, 3), (130, 8)])
+def test_hessian_every_kernel_and_store_path(gpu_lib, n, d, precision):
+    """Both Hessian kernels (matrix core for kernel D >= 10, VALU below), even and odd n_inputs
+    (16-byte and 8-byte store paths), n_inputs below the kernel's D (13 and 14 on the D = 16
+    kernel, 9 on the D = 10 one), ragged row counts; against the oracle, with sentinels after
+    the output and exact symmetry."""
+    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(n * 31 + d, n, d, 83)
+    ref = gp_oracle.hessian(inputs, theta, invQt, testing)
+    ctx = _lib.default_context(0)
+    m = _lib.Model(ctx, np.exp(theta), inputs, invQt, None, precision)
+    M, pad = 83, 32
+    d_t = ctx.to_device(np.ascontiguousarray(testing, dtype=precision))
+    d_h = ctx.to_device(np.full(M * d * d + pad, -9.5, precision))
+    m.hessian_device(d_t, d_h, M)
+    out = ctx.to_host(d_h, (M * d * d + pad,), precision)
+    ctx.free(d_t)
+    ctx.free(d_h)
+    m.close()
+    assert np.all(out[M * d * d:] == -9.5)
+    h = out[:M * d * d].reshape(M, d, d)
+    assert gp_oracle.maxnorm_err(ref, h) <= TOL[precision]
+    assert np.array_equal(h, np.transpose(h, (0, 2, 1)))
+
+
 def test_hessian_real_emulator(gpu_lib):
     g = load_golden("prosail_pc0")
     gp = make_gp(g)
