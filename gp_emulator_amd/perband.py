@@ -114,6 +114,124 @@ class _GatheredObjective(object):
             self._run(batch, -1)
 
 
+def _lockstep_driver():
+    """scipy's reverse-communication L-BFGS-B entry point (``scipy.optimize._lbfgsb.setulb``, the
+    routine ``fmin_l_bfgs_b`` itself loops over), or None when this scipy does not have the
+    signature written for here (1.15: C translation, integer task codes)."""
+    try:
+        import inspect
+        import scipy
+        from scipy.optimize import _lbfgsb, _lbfgsb_py
+        major, minor = (int(v) for v in scipy.__version__.split(".")[:2])
+        if (major, minor) < (1, 15):
+            return None
+        if "ln_task" not in inspect.getsource(_lbfgsb_py._minimize_lbfgsb):
+            return None
+        return _lbfgsb.setulb
+    except Exception:
+        return None
+
+
+class _Instance(object):
+    """One L-BFGS-B minimisation in reverse communication: the state ``fmin_l_bfgs_b`` keeps in
+    local variables (scipy/optimize/_lbfgsb_py.py, ``_minimize_lbfgsb``), same sizes and defaults
+    (m = 10, maxls = 20, maxfun = maxiter = 15000, no bounds)."""
+    __slots__ = ("e", "k", "x", "f", "g", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave",
+                 "nit", "nfev", "low", "up", "nbd", "last_good", "failed")
+
+    def __init__(self, e, k, x0):
+        n, m = x0.size, 10
+        self.e, self.k = e, k
+        self.x = np.array(x0, dtype=np.float64)
+        self.f = 0.0
+        self.g = np.zeros(n)
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32)
+        self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32)
+        self.isave = np.zeros(44, dtype=np.int32)
+        self.dsave = np.zeros(29)
+        self.low, self.up = np.zeros(n), np.zeros(n)
+        self.nbd = np.zeros(n, dtype=np.int32)
+        self.nit = self.nfev = 0
+        self.last_good = self.x.copy()
+        self.failed = False
+
+
+def _learn_lockstep(setulb, batch_fn, targets, starts, max_batch=4096):
+    """Every (emulator, restart) optimisation advances through scipy's own L-BFGS-B routine, one
+    thread, no callbacks: each instance is stepped until it asks for a cost/gradient, then ALL the
+    requests are evaluated in one batched call.  Iterates are those of ``fmin_l_bfgs_b(factr=0.1,
+    pgtol=1e-20)`` (reference GaussianProcess.py:168-170) because it is the same routine fed the
+    same numbers."""
+    E, n_tries, n = starts.shape
+    factr, pgtol, m, maxls, maxfun, maxiter = 0.1, 1e-20, 10, 20, 15000, 15000
+    live = [_Instance(e, k, starts[e, k]) for e in range(E) for k in range(n_tries)]
+    cost = np.full((E, n_tries), np.inf)
+    theta = np.zeros((E, n_tries, n))
+    launches = evaluations = 0
+    while live:
+        asking, still = [], []
+        for it in live:
+            while True:
+                setulb(m, it.x, it.low, it.up, it.nbd, it.f, it.g, factr, pgtol, it.wa, it.iwa,
+                       it.task, it.lsave, it.isave, it.dsave, maxls, it.ln_task)
+                if it.task[0] == 3:                      # wants f and g at x
+                    if it.nfev and np.array_equal(it.x, it.last_good):
+                        continue                         # same point again: f, g are current
+                    asking.append(it)                    # (what scipy's ScalarFunction cache does)
+                    break
+                if it.task[0] == 1:                      # new iteration
+                    it.nit += 1
+                    if it.nit >= maxiter:
+                        it.task[0], it.task[1] = 5, 504
+                    elif it.nfev > maxfun:
+                        it.task[0], it.task[1] = 5, 502
+                    continue
+                cost[it.e, it.k], theta[it.e, it.k] = it.f, it.x   # converged / stopped
+                break
+        for s0 in range(0, len(asking), max_batch):
+            part = asking[s0:s0 + max_batch]
+            th = np.stack([it.x for it in part])
+            tg = targets[[it.e for it in part]]
+            c, g = batch_fn(th, tg)
+            launches += 1
+            evaluations += len(part)
+            for j, it in enumerate(part):
+                it.nfev += 1
+                if not np.isfinite(c[j]):
+                    # a pivot <= 0: the reference's numpy path raises LinAlgError here and its
+                    # optimiser loop gives the restart up with cost 9999 (:176-181)
+                    cost[it.e, it.k], theta[it.e, it.k] = 9999.0, it.last_good
+                    it.failed = True
+                else:
+                    it.f = float(c[j])
+                    it.g = np.ascontiguousarray(g[j], dtype=np.float64)
+                    it.last_good = it.x.copy()
+        live = [it for it in asking if not it.failed]
+    return cost, theta, launches, evaluations
+
+
+def _leave_set(gps, thetas, inputs, ctx):
+    """Leave every emulator set to its optimum (theta, invQ, invQt), as the reference's
+    learn_hyperparameters does (:207-209); on the GPU a few launches of 128 inverses each."""
+    if ctx is None:
+        for e, gp in enumerate(gps):
+            gp._set_params(thetas[e].copy())
+        return
+    step = 128
+    for s in range(0, len(gps), step):
+        part = gps[s:s + step]
+        tg = np.stack([np.asarray(gp.targets, dtype=np.float64) for gp in part])
+        c, g, invQ, invQt = ctx.likelihood_batch(thetas[s:s + len(part)], inputs, tg, want_inverse=True)
+        for i, gp in enumerate(part):
+            gp.theta = thetas[s + i].copy()
+            gp.invQ, gp.invQt = invQ[i].copy(), invQt[i].copy()
+            gp.current_theta, gp.current_loglikelihood = gp.theta, float(c[i])
+            gp._gpu_models = {}
+
+
 def _finite(cost_grad):
     """A non-finite cost means a pivot of the elimination was <= 0 -- what the reference's numpy
     path reports as LinAlgError (GaussianProcess.py:66) and its optimiser loop catches (:176-181)."""
@@ -123,7 +241,7 @@ def _finite(cost_grad):
 
 
 def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch_fn=None,
-                device=0, verbose=False):
+                device=0, verbose=False, method="auto"):
     """``learn_hyperparameters(n_tries)`` for every GaussianProcess in ``gps`` (per-band
     emulators on the SAME training inputs, tests/test_perband_emulator.py:22-37), with the
     optimisations of all bands and all restarts advancing side by side: ``concurrency``
@@ -138,6 +256,12 @@ def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch
 
     ``batch_fn(thetas, targets) -> (cost, grad)`` replaces the GPU objective (tests use a numpy
     one); ``is_gpu`` must be true otherwise -- there is no silent CPU path.
+
+    ``method``: "lockstep" steps scipy's reverse-communication L-BFGS-B routine directly for every
+    (emulator, restart) from one thread and evaluates all pending requests per round in one
+    launch -- the same iterates as ``fmin_l_bfgs_b`` at a fraction of its per-call Python cost;
+    "threads" runs ``concurrency`` ordinary ``fmin_l_bfgs_b`` calls in threads and gathers their
+    requests; "auto" takes lockstep when this scipy exposes the routine with the known signature.
     """
     import threading
     import warnings
@@ -162,6 +286,23 @@ def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch
         starts = np.stack([5. * (np.random.rand(n_tries, D + 2) - 0.5) for _ in range(E)])
     starts = np.asarray(starts, dtype=np.float64).reshape(E, -1, D + 2)
     n_tries = starts.shape[1]
+    setulb = _lockstep_driver() if method in ("auto", "lockstep") else None
+    if method == "lockstep" and setulb is None:
+        raise RuntimeError("this scipy does not expose the L-BFGS-B routine learn_bands knows how to drive")
+    if method not in ("auto", "lockstep", "threads"):
+        raise ValueError("method must be 'auto', 'lockstep' or 'threads'")
+    if setulb is not None:
+        tg_all = np.stack([np.asarray(gp.targets, dtype=np.float64) for gp in gps])
+        best_cost, best_theta, launches, evaluations = _learn_lockstep(setulb, batch_fn, tg_all, starts)
+        pick = np.argmin(best_cost, axis=1)
+        costs = best_cost[np.arange(E), pick]
+        thetas = best_theta[np.arange(E), pick]
+        _leave_set(gps, thetas, inputs, ctx)
+        stats = {"launches": launches, "evaluations": evaluations, "threads": 1, "method": "lockstep"}
+        if verbose:
+            print("learn_bands: %d emulators x %d starts, %d evaluations in %d launches" % (
+                E, n_tries, evaluations, launches))
+        return costs, thetas, stats
     jobs = Queue()
     for e in range(E):
         for k in range(n_tries):
@@ -203,22 +344,9 @@ def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch
     pick = np.argmin(best_cost, axis=1)
     costs = best_cost[np.arange(E), pick]
     thetas = best_theta[np.arange(E), pick]
-    # leave every emulator set to its optimum: invQ / invQt for all bands, a few launches
-    if ctx is not None:
-        step = 128
-        for s in range(0, E, step):
-            sl = slice(s, min(E, s + step))
-            tg = np.stack([np.asarray(gp.targets, dtype=np.float64) for gp in gps[sl]])
-            c, g, invQ, invQt = ctx.likelihood_batch(thetas[sl], inputs, tg, want_inverse=True)
-            for i, gp in enumerate(gps[sl]):
-                gp.theta = thetas[s + i].copy()
-                gp.invQ, gp.invQt = invQ[i].copy(), invQt[i].copy()
-                gp.current_theta, gp.current_loglikelihood = gp.theta, float(c[i])
-                gp._gpu_models = {}
-    else:
-        for e, gp in enumerate(gps):
-            gp._set_params(thetas[e].copy())
-    stats = {"launches": gather.launches, "evaluations": gather.evaluations, "threads": n_threads}
+    _leave_set(gps, thetas, inputs, ctx)
+    stats = {"launches": gather.launches, "evaluations": gather.evaluations, "threads": n_threads,
+             "method": "threads"}
     if verbose:
         print("learn_bands: %d emulators x %d starts, %d evaluations in %d launches" % (
             E, n_tries, gather.evaluations, gather.launches))

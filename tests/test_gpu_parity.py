@@ -667,7 +667,12 @@ def test_learn_bands_on_gpu_matches_sequential(gpu_lib):
     gps = [GaussianProcess(X, t) for t in bands]
     np.random.seed(21)
     costs, thetas, stats = perband.learn_bands(gps, n_tries=2, concurrency=12)
-    assert stats["threads"] == 12 and stats["evaluations"] / stats["launches"] > 4
+    assert stats["evaluations"] / stats["launches"] > 4
+    gps_t = [GaussianProcess(X, t) for t in bands]            # the other driver: same thetas
+    np.random.seed(21)
+    costs_t, thetas_t, stats_t = perband.learn_bands(gps_t, n_tries=2, concurrency=12, method="threads")
+    assert stats_t["method"] == "threads" and stats_t["threads"] == 12
+    assert np.allclose(costs, costs_t, rtol=1e-9) and np.allclose(thetas, thetas_t, rtol=1e-6, atol=1e-6)
     np.random.seed(21)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -117,20 +117,29 @@ def _numpy_objective(X, calls):
     return fn
 
 
-def test_learn_bands_matches_a_loop_of_learn_hyperparameters():
+@pytest.mark.parametrize("method", ["lockstep", "threads"])
+def test_learn_bands_matches_a_loop_of_learn_hyperparameters(method):
     """Same starting points (drawn in the same order from numpy.random), same optimiser, batched
     objective: every band ends at the optimum the reference-style loop finds, and the requests
-    really were gathered (several per call of the objective)."""
+    really were gathered (several per call of the objective).  "lockstep" drives scipy's
+    reverse-communication routine directly, "threads" gathers the requests of fmin_l_bfgs_b
+    calls running in threads."""
     import warnings
     from gp_emulator_amd import GaussianProcess, perband
+    if method == "lockstep" and perband._lockstep_driver() is None:
+        pytest.skip("this scipy does not expose the reverse-communication routine")
     X, bands = _bands_problem()
     gps = [GaussianProcess(X, t) for t in bands]
     calls = []
     np.random.seed(11)
-    costs, thetas, stats = perband.learn_bands(gps, n_tries=2, concurrency=4,
+    costs, thetas, stats = perband.learn_bands(gps, n_tries=2, concurrency=4, method=method,
                                                batch_fn=_numpy_objective(X, calls))
-    assert stats["threads"] == 4 and stats["evaluations"] == sum(calls) and stats["launches"] == len(calls)
-    assert max(calls) == 4 and sum(calls) / len(calls) > 2.0
+    assert stats["method"] == method
+    assert stats["evaluations"] == sum(calls) and stats["launches"] == len(calls)
+    if method == "threads":
+        assert stats["threads"] == 4 and max(calls) == 4 and sum(calls) / len(calls) > 2.0
+    else:
+        assert max(calls) == 10 and sum(calls) / len(calls) > 4.0      # 5 bands x 2 starts at once
     np.random.seed(11)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -156,11 +165,33 @@ def test_learn_bands_edge_cases():
 
     def broken(thetas, targets):
         raise RuntimeError("objective failed")
-    with pytest.raises(RuntimeError):                                 # every thread is released
-        perband.learn_bands(gps, n_tries=2, concurrency=3, batch_fn=broken)
+    for method in ("threads", "auto"):
+        with pytest.raises(RuntimeError):                             # every thread is released
+            perband.learn_bands(gps, n_tries=2, concurrency=3, batch_fn=broken, method=method)
     # more threads than problems, explicit starts, one try
     calls = []
     starts = np.zeros((3, 1, 4))
-    costs, thetas, stats = perband.learn_bands(gps, concurrency=64, starts=starts,
+    costs, thetas, stats = perband.learn_bands(gps, concurrency=64, starts=starts, method="threads",
                                                batch_fn=_numpy_objective(X, calls))
     assert stats["threads"] == 3 and costs.shape == (3,) and thetas.shape == (3, 4)
+    with pytest.raises(ValueError):
+        perband.learn_bands(gps, starts=starts, method="bogus", batch_fn=_numpy_objective(X, calls))
+
+
+def test_learn_bands_lockstep_equals_threads_bit_for_bit():
+    """Both drivers feed the same numbers to the same L-BFGS-B routine: identical thetas, and the
+    same number of objective evaluations (repeated requests at an unchanged point are served
+    from the last result, as scipy's own wrapper does)."""
+    from gp_emulator_amd import GaussianProcess, perband
+    if perband._lockstep_driver() is None:
+        pytest.skip("this scipy does not expose the reverse-communication routine")
+    X, bands = _bands_problem(n_bands=4)
+    out = {}
+    for method in ("lockstep", "threads"):
+        gps = [GaussianProcess(X, t) for t in bands]
+        np.random.seed(5)
+        out[method] = perband.learn_bands(gps, n_tries=2, concurrency=3, method=method,
+                                          batch_fn=_numpy_objective(X, []))
+    assert np.array_equal(out["lockstep"][0], out["threads"][0])
+    assert np.array_equal(out["lockstep"][1], out["threads"][1])
+    assert out["lockstep"][2]["evaluations"] == out["threads"][2]["evaluations"]
