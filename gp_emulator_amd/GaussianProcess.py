@@ -170,19 +170,16 @@ class GaussianProcess:
         params = []
         starts = 5. * (np.random.rand(n_tries, self.D + 2) - 0.5)
         if is_gpu and n_tries > 1:
-            # one evaluation keeps a single workgroup busy, so the restarts run side by side:
-            # a host thread, a context (stream) and a private copy of this object per restart
-            import copy
-            from concurrent.futures import ThreadPoolExecutor
-
-            def one(theta0):
-                worker = copy.copy(self)
-                worker._gpu_models = {}
-                return worker._learn(theta0, verbose, is_gpu=True)
-            with ThreadPoolExecutor(max_workers=min(n_tries, 8)) as ex:
-                results = list(ex.map(one, starts))
-        else:
-            results = [self._learn(theta, verbose, is_gpu=is_gpu) for theta in starts]
+            # one evaluation keeps a single workgroup busy, so the restarts advance together and
+            # every round of cost/gradient requests is one batched launch (perband.learn_bands:
+            # scipy's L-BFGS-B stepped in reverse communication, same starting points)
+            from . import perband
+            costs, thetas, _ = perband.learn_bands([self], starts=starts[None, :, :])
+            if verbose:
+                print("After %d, the minimum cost was %e" % (n_tries, costs[0]))
+            self._last_grad = None
+            return (costs[0], thetas[0])
+        results = [self._learn(theta, verbose, is_gpu=is_gpu) for theta in starts]
         for T in results:
             log_like.append(T[1])
             params.append(T[0])

@@ -226,6 +226,8 @@ def _leave_set(gps, thetas, inputs, ctx):
         tg = np.stack([np.asarray(gp.targets, dtype=np.float64) for gp in part])
         c, g, invQ, invQt = ctx.likelihood_batch(thetas[s:s + len(part)], inputs, tg, want_inverse=True)
         for i, gp in enumerate(part):
+            if not np.isfinite(c[i]):     # every restart failed: the reference's final
+                raise np.linalg.LinAlgError("Matrix is not positive definite")   # loglikelihood raises too
             gp.theta = thetas[s + i].copy()
             gp.invQ, gp.invQt = invQ[i].copy(), invQt[i].copy()
             gp.current_theta, gp.current_loglikelihood = gp.theta, float(c[i])
