@@ -25,3 +25,13 @@ for flag in (False, True):
         mv = MultivariateEmulator(is_gpu=flag, **kw)
         best = min(best, time.perf_counter() - t0)
     print("set up 12 PC emulators (N=250, D=10), is_gpu=%s: %.1f ms" % (flag, best * 1e3))
+
+# the same emulator trained from scratch (hyperparams=None: learn_hyperparameters for every PC,
+# reference multivariate_gp.py:180-184), all PCs and restarts together on the GPU
+import warnings
+warnings.simplefilter("ignore")
+kw2 = dict(X=X, y=g["y_train"], basis_functions=g["basis_functions"], n_pcs=int(g["n_pcs"]), n_tries=5)
+np.random.seed(0)
+t0 = time.perf_counter()
+mv = MultivariateEmulator(is_gpu=True, **kw2)
+print("train 12 PC emulators x 5 restarts (N=250, D=10), is_gpu=True: %.2f s" % (time.perf_counter() - t0))
