@@ -364,7 +364,7 @@ def main():
         # folded variance = 4 NB(NB+1)/2 MFMAs of 16x16x4 per 16-row tile; Hessian = D(D+1)/2 fmas
         # per (training point, test point) over the padded training set
         nb_pad = model.info()["kernel_nb"] if kind != "hessian" else (N + 15) // 16
-        hess_mfma = (kind == "hessian" and model.info()["kernel_d"] in (10, 11, 12, 16)
+        hess_mfma = (kind == "hessian" and model.info()["kernel_d"] in (8, 10, 11, 12, 16)
                      and model.info()["kernel_nb"] > 0 and not int(os.environ.get("GP_HESS_VALU", "0")))
         if hess_mfma:
             # 4 x 4 blocks (bi <= bj) of the D x D matrix, 4 NB MFMAs of 16x16x4 each per 16-row tile

@@ -526,7 +526,7 @@ static bool hessian_on_matrix_core(const gp_model* m) {
   if (m->kernel_nb <= 0 || m->n_emulators != 1 || m->xs_host.empty()) return false;
   if (const char* ev = getenv("GP_HESS_VALU"))      // A/B switch: force the VALU kernel
     if (atoi(ev) != 0) return false;
-  return m->kernel_d == 10 || m->kernel_d == 11 || m->kernel_d == 12 || m->kernel_d == 16;
+  return m->kernel_d == 8 || m->kernel_d == 10 || m->kernel_d == 11 || m->kernel_d == 12 || m->kernel_d == 16;
 }
 
 // The constant operand of hessian_mfma_kernel, built once per model: P[i][(d, d2)] =

@@ -7,10 +7,11 @@
 //   hess[d][d2] = sd_d sd_d2 * sum_i w_i delta_id delta_id2  -  [d == d2] e_d * sum_i w_i
 //
 // i.e. a symmetric rank-N update per test row, done here on the VALU with D(D+1)/2 fmas per
-// (training point, test row).  This is the kernel for n_inputs < 10; from kernel D = 10 up the
+// (training point, test row).  This is the kernel for n_inputs <= 5; from kernel D = 8 up the
 // same quantity is computed on the matrix core by gp_hessian_mfma_kernel.hpp (the pair products
 // x''_id x''_id2 do not depend on the test row, which turns the sum into a matrix product), which
-// is 1.4x faster at D = 16.  GP_HESS_VALU=1 in the environment forces this kernel for every D.
+// is 1.2-1.5x faster at D = 8, 12 and 16 (even at D = 10, 11 in fp64, where 4 x 4 blocks pad 55 / 66
+// products to 96).  GP_HESS_VALU=1 in the environment forces this kernel for every D.
 //
 // Lane layout as in the predict kernel: lane l works for test row (l & 15) and the quarter
 // (l >> 4) of the training points; the D(D+1)/2 partial sums live in registers (one wave

@@ -1,5 +1,6 @@
 // One translation unit per (compute dtype, NB): hessian_mfma_kernel<T, D, NB> for the kernel
-// dimensions where the matrix-core form beats the VALU one (D >= 10).  Compiled by build.py with
+// dimensions where the matrix-core form beats (or ties with) the VALU one (D >= 8;
+// profiles/r01_hessian_kernels.txt).  Compiled by build.py with
 // -DGP_T=<float|double> -DGP_TNAME=<f32|f64> -DGP_NB=<blocks of 16 training points>.
 #include "gp_hessian_mfma_kernel.hpp"
 
@@ -17,6 +18,7 @@ static hipError_t launch_one(const HessMfmaArgs<GP_T>& a, int grid, hipStream_t 
 hipError_t GP_CAT(launch_hessm_, GP_TNAME, GP_NB)(int kernel_d, const HessMfmaArgs<GP_T>& a,
                                                  int grid, hipStream_t stream) {
   switch (kernel_d) {
+    case 8: return launch_one<8>(a, grid, stream);
     case 10: return launch_one<10>(a, grid, stream);
     case 11: return launch_one<11>(a, grid, stream);
     case 12: return launch_one<12>(a, grid, stream);
