@@ -151,7 +151,10 @@ int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
  * Replaces GaussianProcess.hessian (gp_emulator/GaussianProcess.py:345-366; the reference
  * has NO native version of it).  hess is (n_predict, n_inputs, n_inputs) row-major.
  * gp_hessian_device: device pointers, asynchronous on the context's stream.
- * gp_hessian_f64/_f32: host pointers in and out (invQ is not needed by the Hessian). */
+ * gp_hessian_f64/_f32: host pointers in and out (invQ is not needed by the Hessian).
+ * Every element and its mirror image are stored from the same value: the result is exactly
+ * symmetric.  n_inputs >= 6 (with n_train <= 320) runs on the matrix core; the first Hessian
+ * call on a model packs and uploads that kernel's constant operand (once, thread-safe). */
 int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
                       void* d_hess, int64_t n_predict);
 int gp_hessian_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
