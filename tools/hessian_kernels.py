@@ -12,13 +12,13 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gp_emulator_amd import _lib  # noqa: E402
-from oracle import gp_oracle  # noqa: E402  (seeded synthetic inputs only)
+from bench import synthetic_inputs  # noqa: E402  (seeded synthetic inputs)
 
 ctx = _lib.default_context(0)
 M = 1000000
 print("GP_HESS_VALU=%s" % os.environ.get("GP_HESS_VALU", "0"))
 for N, D in ((250, 8), (250, 10), (250, 11), (300, 12), (300, 16), (120, 8)):
-    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1, N, D, M)
+    inputs, testing, theta, invQ, invQt = synthetic_inputs(1, N, D, M)
     for prec in (np.float64, np.float32):
         m = _lib.Model(ctx, np.exp(theta), inputs, invQt, None, prec)
         d_t = ctx.to_device(np.ascontiguousarray(testing, dtype=prec))

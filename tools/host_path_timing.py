@@ -4,11 +4,11 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gp_emulator_amd import GaussianProcess, _lib
-from oracle import gp_oracle
+from bench import synthetic_inputs
 
 N, D = 250, 11
 for M in (100000, 1000000):
-    inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1, N, D, M)
+    inputs, testing, theta, invQ, invQt = synthetic_inputs(1, N, D, M)
     gp = GaussianProcess(inputs, [])
     gp.theta, gp.invQ, gp.invQt = theta, invQ, invQt
     for prec in (np.float64, np.float32):

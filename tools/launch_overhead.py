@@ -3,11 +3,11 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gp_emulator_amd import _lib
-from oracle import gp_oracle
+from bench import synthetic_inputs
 
 ctx = _lib.Context(0)
 M = 1000000
-inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1, 250, 11, M)
+inputs, testing, theta, invQ, invQt = synthetic_inputs(1, 250, 11, M)
 model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, np.float64)
 d_t = ctx.to_device(testing)
 d_mu, d_var, d_der = ctx.malloc(M * 8), ctx.malloc(M * 8), ctx.malloc(M * 88)

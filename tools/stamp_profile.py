@@ -5,14 +5,14 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gp_emulator_amd import _lib
-from oracle import gp_oracle
+from bench import synthetic_inputs
 
 ctx = _lib.Context(0)
 DT = np.float32 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else np.float64
 ISZ = np.dtype(DT).itemsize
 WAVES = 12 if DT == np.float32 else 8
 M = 1000000
-inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(1, 250, 11, M)
+inputs, testing, theta, invQ, invQt = synthetic_inputs(1, 250, 11, M)
 model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, DT)
 d_t = ctx.to_device(testing.astype(DT))
 d_mu, d_var, d_der = ctx.malloc(M * ISZ), ctx.malloc(M * ISZ), ctx.malloc(M * 11 * ISZ)
