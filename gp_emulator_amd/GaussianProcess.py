@@ -46,9 +46,10 @@ def k_fold_cross_validation(X, K, randomise=False):
 class GaussianProcess:
     """Squared-exponential ARD Gaussian-process emulator (predict side)."""
 
-    # gpu_predict crosses the boundary with predict_rows (row-major gradient written
-    # straight into the arrays it returns) unless this is False, in which case it calls
-    # the reference's predict_wrap and un-transposes, exactly as reference :313-321.
+    # True: gpu_predict makes ONE call on a device-resident model (gp_predict_host: constants
+    # uploaded once per emulator, rows through the library's slab pipeline, row-major gradient
+    # written straight into the array it returns).  False: the reference's own flow, block by
+    # block through the twelve-argument predict_wrap with the un-transpose of :313-321.
     row_major_boundary = True
 
     def __init__(self, inputs, targets):
@@ -238,21 +239,33 @@ class GaussianProcess:
         ``threshold`` only bounds the block size; the kernel itself has no 2e5-row limit
         (the reference's came from kernel_matrixExp.cu:29).
         """
-        from . import _gpu_predict
         precision = np.dtype(precision)
+        if precision not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("precision must be float32 or float64, got %r" % (precision,))
         n_predict, n_inputs = testing.shape
+        assert n_inputs == self.D
+        if self.row_major_boundary:
+            # One library call: the constants are packed and uploaded once per emulator
+            # (gpu_model), the rows flow through the library's slab pipeline with at most
+            # ``threshold`` rows per launch, and the row-major gradient lands in the array that
+            # is returned -- no per-block upload, append or transpose (reference :297-321).
+            # float32 on float64 data: the library converts while it stages.
+            testing = np.asarray(testing)
+            if testing.dtype != np.float64:
+                testing = testing.astype(precision)
+            model = self.gpu_model(precision)
+            result, error, deriv = model.predict(testing, max_block_rows=int(threshold))
+            if result.dtype != np.float64:   # the reference's outputs are float64 (:318-321)
+                result, error, deriv = (a.astype(np.float64) for a in (result, error, deriv))
+            return result, error, deriv
+
+        # The reference's own flow, block by block through its twelve-argument boundary.
+        from . import _gpu_predict
         n_train = self.inputs.shape[0]
         theta_size = self.theta.size
-        assert n_inputs == self.D
-
-        # float32 predict on float64 data through the row-major boundary: the library converts
-        # while it stages, nothing is cast on the host
-        mixed = (self.row_major_boundary and precision == np.float32
-                 and np.asarray(testing).dtype == np.float64)
-        host_dt = np.dtype(np.float64) if mixed else precision
 
         def cast(a, size):   # 1-D, contiguous, ``precision`` (reference :289-292)
-            return np.ascontiguousarray(np.asarray(a).reshape(size), dtype=host_dt)
+            return np.ascontiguousarray(np.asarray(a).reshape(size), dtype=precision)
         inputs = cast(self.inputs, n_train * n_inputs)
         invQt = cast(self.invQt, n_train)
         invQ = cast(self.invQ, n_train * n_train)
@@ -262,32 +275,16 @@ class GaussianProcess:
         error = np.empty(n_predict)
         deriv = np.empty((n_predict, n_inputs))
         ind_start, ind_end = self.get_gpu_block(n_predict, threshold)
-        direct = self.row_major_boundary and host_dt == np.float64
-        rows_fn = _gpu_predict.predict_rows_f32_h64 if mixed else _gpu_predict.predict_rows
         for block_start, block_end in zip(ind_start, ind_end):
             n_blk = int(block_end - block_start)
             testing_block = cast(testing[block_start:block_end, :], n_blk * n_inputs)
-            if direct:
-                # float64: the library writes into the final arrays' own slices
-                rows_fn(expX, inputs, invQt, invQ, testing_block,
-                                          result[block_start:block_end],
-                                          error[block_start:block_end],
-                                          deriv[block_start:block_end, :].reshape(-1),
-                                          n_blk, n_train, n_inputs, theta_size)
-                continue
             result_block = np.zeros(n_blk, dtype=precision)
             error_block = np.zeros(n_blk, dtype=precision)
             deriv_block = np.zeros(n_blk * n_inputs, dtype=precision)
-            if self.row_major_boundary:
-                _gpu_predict.predict_rows(expX, inputs, invQt, invQ, testing_block,
-                                          result_block, error_block, deriv_block,
-                                          n_blk, n_train, n_inputs, theta_size)
-                deriv[block_start:block_end, :] = deriv_block.reshape(n_blk, n_inputs)
-            else:
-                _gpu_predict.predict_wrap(expX, inputs, invQt, invQ, testing_block,
-                                          result_block, error_block, deriv_block,
-                                          n_blk, n_train, n_inputs, theta_size)
-                deriv[block_start:block_end, :] = deriv_block.reshape(n_inputs, n_blk).T
+            _gpu_predict.predict_wrap(expX, inputs, invQt, invQ, testing_block,
+                                      result_block, error_block, deriv_block,
+                                      n_blk, n_train, n_inputs, theta_size)
+            deriv[block_start:block_end, :] = deriv_block.reshape(n_inputs, n_blk).T
             result[block_start:block_end] = result_block
             error[block_start:block_end] = error_block
         return result, error, deriv
@@ -301,42 +298,42 @@ class GaussianProcess:
 
     # ------------------------------------------------------------------ device-resident use
     def gpu_model(self, precision=np.float64, device=0):
-        """Constants packed and uploaded once (cached per precision/device): the form to use
-        when predict is called repeatedly or the test rows already live in HBM."""
+        """Constants packed and uploaded once (cached per precision/device): what ``predict``
+        and ``hessian`` run on, and the form to use when the test rows already live in HBM.
+        The cache entry remembers the constants it was built from and is rebuilt when theta,
+        inputs, invQt or invQ no longer compare equal (they are plain attributes, as in the
+        reference, and callers assign them)."""
         from . import _lib
         key = (np.dtype(precision).str, int(device))
-        m = self._gpu_models.get(key)
-        if m is None:
-            ctx = _lib.default_context(device)
-            m = _lib.Model(ctx, np.exp(self.theta), self.inputs, self.invQt, self.invQ, precision)
-            self._gpu_models[key] = m
+        invQ = getattr(self, "invQ", None)        # absent: a model for the Hessian alone
+        consts = (np.asarray(self.theta), np.asarray(self.inputs), np.asarray(self.invQt),
+                  np.asarray(invQ) if invQ is not None else np.empty(0))
+        hit = self._gpu_models.get(key)
+        if hit is not None:
+            m, kept = hit
+            if all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(consts, kept)):
+                return m
+            m.close()
+        ctx = _lib.default_context(device)
+        m = _lib.Model(ctx, np.exp(self.theta), self.inputs, self.invQt, invQ, precision)
+        self._gpu_models[key] = (m, tuple(np.array(a, copy=True) for a in consts))
         return m
 
     # ------------------------------------------------------------------ Hessian
     def hessian(self, testing, is_gpu=False, precision=np.float64):
         """(nn, D, D) Hessian of the mean (reference :345-366, which is numpy only and takes
         just ``testing``).  ``is_gpu=True`` runs the fused HIP kernel through the C ABI
-        (``gp_hessian_f64/_f32``) and, like ``predict``, never falls back to the CPU.
+        (``gp_hessian_host`` on the cached device model) and, like ``predict``, never falls back to the CPU.
         ``is_gpu=False`` is the explicit numpy branch, written as the symmetric rank-N update
         it is: H = sum_i w_i u_i u_i^T - diag(e) mu,  w = a * invQt,  u_i = e * (x_i - t)."""
         (nn, D) = testing.shape
         assert D == self.D
         if is_gpu == True:  # noqa: E712
-            from . import _lib
             dt = np.dtype(precision)
-            ctx = _lib.default_context(0)
-            fn = ctx.lib.gp_hessian_f64 if dt == np.float64 else ctx.lib.gp_hessian_f32
             if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
                 raise TypeError("precision must be float32 or float64")
-
-            def cast(a):
-                return np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=dt)
-            expX, inputs, invQt, t = (cast(np.exp(self.theta)), cast(self.inputs),
-                                      cast(self.invQt), cast(testing))
-            hess = np.zeros(nn * D * D, dtype=dt)
-            p = [a.ctypes.data_as(_lib.c_void_p) for a in (expX, inputs, invQt, t, hess)]
-            _lib.check(fn(ctx.h, *p, nn, self.inputs.shape[0], D, self.theta.size), "gp_hessian")
-            return hess.reshape(nn, D, D).astype(np.float64, copy=False)
+            hess = self.gpu_model(dt).hessian(np.asarray(testing))
+            return hess.astype(np.float64, copy=False)
         expX = np.exp(self.theta)
         s = np.sqrt(expX[:D])
         a = expX[D] * np.exp(-0.5 * dist.cdist(s * self.inputs, s * testing, "sqeuclidean"))

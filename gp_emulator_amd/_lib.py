@@ -6,6 +6,7 @@ built or no GPU is visible -- there is no CPU fallback anywhere behind ``is_gpu=
 """
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -41,6 +42,8 @@ SIGNATURES = {
     "gp_predict_rows_f32_h64": (c_int, [c_void_p] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_int]),
     "gp_model_create_f64": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_model_create_f32": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
+    "gp_model_create_f32_h64": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
+    "gp_batch_create_f32_h64": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_batch_create_f64": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_batch_create_f32": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, PP]),
     "gp_model_emulators": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
@@ -48,7 +51,12 @@ SIGNATURES = {
     "gp_model_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5),
     "gp_predict_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_i64, c_int]),
+    "gp_predict_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_i64, c_int, c_i64]),
+    "gp_ctx_host_threads": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "gp_kernel_ksteps": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "gp_hessian_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
+    "gp_hessian_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
     "gp_hessian_f64": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_hessian_f32": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_reconstruct_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int]),
@@ -123,6 +131,53 @@ def _ptr(a):
     return a.ctypes.data_as(c_void_p)
 
 
+class OutputPool:
+    """Recycles the memory of predict's output arrays.
+
+    A fresh 100 MB numpy array costs more than the predict that fills it: every page is
+    first-touch faulted while the results are copied in, and unmapped again (with TLB shootdowns
+    to every helper thread's core) when the caller drops it -- 7 ms per 1e6 float64 rows on the
+    GPU box against 4 ms for the whole predict.  So the arrays ``Model.predict`` returns are views
+    of pooled buffers, and a buffer is handed out again once nothing but the pool refers to it
+    (``sys.getrefcount``): a caller that keeps its results keeps their memory, a loop that drops
+    them runs on warm pages.  Buffers over ``max_item`` bytes are never pooled and the pool holds
+    at most ``max_total`` bytes."""
+
+    def __init__(self, max_item=256 << 20, max_total=1 << 30):
+        self.max_item, self.max_total = max_item, max_total
+        self.items = []
+
+    def take(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < (1 << 20) or nbytes > self.max_item:
+            return np.empty(shape, dtype)
+        base = None
+        for cand in self.items:
+            # references to a free buffer: the pool's list, ``cand`` and getrefcount's argument
+            if cand.nbytes == nbytes and sys.getrefcount(cand) == 3:
+                base = cand
+                break
+        cand = None
+        if base is None:
+            base = np.empty(nbytes, np.uint8)
+            self.items.append(base)
+            total = sum(b.nbytes for b in self.items)
+            # over budget: forget buffers (free ones first); memory still in use stays alive through
+            # its users' references and is simply no longer recycled
+            for free_first in (True, False):
+                i = 0
+                while total > self.max_total and i < len(self.items):
+                    b = self.items[i]
+                    if b is not base and (not free_first or sys.getrefcount(b) == 3):
+                        total -= b.nbytes
+                        del self.items[i]
+                    else:
+                        i += 1
+                b = None
+        return base.view(dtype).reshape(shape)
+
+
 class Context:
     """One device + one HIP stream (gp_ctx).  Use one per thread / per GPU."""
 
@@ -135,6 +190,7 @@ class Context:
             raise GpuPredictUnavailable("no usable GPU context on device %d: %s" % (device, msg))
         self.h = h
         self.device = int(device)
+        self.out_pool = OutputPool()
 
     def close(self):
         if getattr(self, "h", None):
@@ -151,6 +207,11 @@ class Context:
         name = ctypes.create_string_buffer(256)
         check(self.lib.gp_ctx_device_info(self.h, ctypes.byref(cu), ctypes.byref(mem), name, 256))
         return dict(compute_units=cu.value, hbm_bytes=mem.value, name=name.value.decode())
+
+    def host_threads(self):
+        n = c_int(0)
+        check(self.lib.gp_ctx_host_threads(self.h, ctypes.byref(n)), "gp_ctx_host_threads")
+        return n.value
 
     # ---- memory -----------------------------------------------------------------
     def malloc(self, nbytes):
@@ -232,19 +293,21 @@ class Model:
         self.dtype = np.dtype(precision)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise TypeError("precision must be float32 or float64, got %r" % (precision,))
-        inputs = np.ascontiguousarray(inputs, dtype=self.dtype)
+        # constants cross the boundary as float64 whatever the compute type: a float32 model is
+        # packed from the float64 values and rounded once (gp_model_create_f32_h64)
+        inputs = np.ascontiguousarray(inputs, dtype=np.float64)
         if inputs.ndim != 2:
             raise ValueError("inputs must be (n_train, n_inputs)")
         self.n_train, self.n_inputs = inputs.shape
-        expX = np.ascontiguousarray(expX, dtype=self.dtype).ravel()
-        invQt = np.ascontiguousarray(invQt, dtype=self.dtype).ravel()
+        expX = np.ascontiguousarray(expX, dtype=np.float64).ravel()
+        invQt = np.ascontiguousarray(invQt, dtype=np.float64).ravel()
         if invQt.size != self.n_train:
             raise ValueError("invQt size does not match n_train")
         if invQ is not None:             # None: Hessian-only model (no variance operand)
-            invQ = np.ascontiguousarray(invQ, dtype=self.dtype)
+            invQ = np.ascontiguousarray(invQ, dtype=np.float64)
             if invQ.size != self.n_train ** 2:
                 raise ValueError("invQ size does not match n_train")
-        fn = ctx.lib.gp_model_create_f64 if self.dtype == np.float64 else ctx.lib.gp_model_create_f32
+        fn = ctx.lib.gp_model_create_f64 if self.dtype == np.float64 else ctx.lib.gp_model_create_f32_h64
         h = c_void_p()
         check(fn(ctx.h, _ptr(expX), _ptr(inputs), _ptr(invQt),
                  _ptr(invQ) if invQ is not None else None,
@@ -263,29 +326,44 @@ class Model:
         check(self.ctx.lib.gp_predict_device(self.ctx.h, self.h, d_testing, d_mu, d_var, d_deriv,
                                              int(n_predict), int(deriv_layout)), "gp_predict_device")
 
-    def predict(self, testing, deriv_layout=GP_DERIV_ROWMAJOR):
-        """Host arrays in, host arrays out, through device buffers owned by this call."""
-        testing = np.ascontiguousarray(testing, dtype=self.dtype)
+    def predict(self, testing, deriv_layout=GP_DERIV_ROWMAJOR, out=None, max_block_rows=0):
+        """Host arrays in, host arrays out through the library's slab pipeline
+        (``gp_predict_host``: pinned staging, three slots, helper threads).
+
+        ``testing`` is (M, D) of the model's dtype, or float64 for a float32 model (rows are
+        then centred and scaled in double while they are staged, and the outputs come back as
+        float64).  ``out=(mu, var, deriv)`` supplies the output arrays (contiguous, dtype of
+        ``testing``); without it the arrays come from the context's ``OutputPool`` (memory of
+        results the caller has dropped is reused).  ``max_block_rows`` > 0 bounds the rows per
+        launch."""
+        testing = np.asarray(testing)
+        if testing.dtype != np.float64 or self.dtype == np.float64:
+            testing = np.ascontiguousarray(testing, dtype=self.dtype)
+        else:
+            testing = np.ascontiguousarray(testing)
+        hdt = testing.dtype
+        if testing.ndim != 2:
+            raise ValueError("testing must be (n_predict, n_inputs)")
         M, D = testing.shape
         if D != self.n_inputs:
             raise ValueError("testing has %d columns, model has %d inputs" % (D, self.n_inputs))
-        isz = self.dtype.itemsize
-        if M == 0:
-            shape = (0, D) if deriv_layout == GP_DERIV_ROWMAJOR else (D, 0)
-            return (np.empty(0, self.dtype), np.empty(0, self.dtype), np.empty(shape, self.dtype))
-        d_t = self.ctx.to_device(testing)
-        d_mu = self.ctx.malloc(M * isz)
-        d_var = self.ctx.malloc(M * isz)
-        d_der = self.ctx.malloc(M * D * isz)
-        try:
-            self.predict_device(d_t, d_mu, d_var, d_der, M, deriv_layout)
-            mu = self.ctx.to_host(d_mu, (M,), self.dtype)
-            var = self.ctx.to_host(d_var, (M,), self.dtype)
-            shape = (M, D) if deriv_layout == GP_DERIV_ROWMAJOR else (D, M)
-            deriv = self.ctx.to_host(d_der, shape, self.dtype)
-        finally:
-            for p in (d_t, d_mu, d_var, d_der):
-                self.ctx.free(p)
+        E = getattr(self, "n_emulators", None)
+        lead = () if E is None else (E,)
+        dshape = lead + ((M, D) if deriv_layout == GP_DERIV_ROWMAJOR else (D, M))
+        if out is None:
+            take = self.ctx.out_pool.take
+            mu, var, deriv = take(lead + (M,), hdt), take(lead + (M,), hdt), take(dshape, hdt)
+        else:
+            mu, var, deriv = out
+            for a, shape in ((mu, lead + (M,)), (var, lead + (M,)), (deriv, dshape)):
+                if (not isinstance(a, np.ndarray) or a.dtype != hdt or a.shape != shape
+                        or not a.flags["C_CONTIGUOUS"] or not a.flags["WRITEABLE"]):
+                    raise ValueError("out arrays must be writeable C-contiguous %s arrays of shapes "
+                                     "%s, %s, %s" % (hdt, lead + (M,), lead + (M,), dshape))
+        if M:
+            check(self.ctx.lib.gp_predict_host(
+                self.ctx.h, self.h, GP_F64 if hdt == np.float64 else GP_F32, _ptr(testing), _ptr(mu),
+                _ptr(var), _ptr(deriv), M, int(deriv_layout), int(max_block_rows)), "gp_predict_host")
         return mu, var, deriv
 
     def hessian_device(self, d_testing, d_hess, n_predict):
@@ -293,21 +371,19 @@ class Model:
         check(self.ctx.lib.gp_hessian_device(self.ctx.h, self.h, d_testing, d_hess,
                                              int(n_predict)), "gp_hessian_device")
 
-    def hessian(self, testing):
+    def hessian(self, testing, out=None):
+        """(M, D, D) Hessian of the mean for host rows, through the slab pipeline."""
         testing = np.ascontiguousarray(testing, dtype=self.dtype)
         M, D = testing.shape
         if D != self.n_inputs:
             raise ValueError("testing has %d columns, model has %d inputs" % (D, self.n_inputs))
-        if M == 0:
-            return np.empty((0, D, D), self.dtype)
-        d_t = self.ctx.to_device(testing)
-        d_h = self.ctx.malloc(M * D * D * self.dtype.itemsize)
-        try:
-            self.hessian_device(d_t, d_h, M)
-            return self.ctx.to_host(d_h, (M, D, D), self.dtype)
-        finally:
-            self.ctx.free(d_t)
-            self.ctx.free(d_h)
+        hess = self.ctx.out_pool.take((M, D, D), self.dtype) if out is None else out
+        if hess.shape != (M, D, D) or hess.dtype != self.dtype or not hess.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous (M, D, D) array of the model's dtype")
+        if M:
+            check(self.ctx.lib.gp_hessian_host(self.ctx.h, self.h, _ptr(testing), _ptr(hess), M),
+                  "gp_hessian_host")
+        return hess
 
     def close(self):
         if getattr(self, "h", None):
@@ -322,7 +398,7 @@ class BatchModel(Model):
     tests/test_perband_emulator.py:22-37), predicted over shared test rows in ONE launch.
 
     expX (E, D+2), inputs (N, D), invQt (E, N), invQ (E, N, N).
-    ``predict`` returns mu (E, M), var (E, M), deriv (E, M, D).
+    ``predict`` (inherited: the slab pipeline) returns mu (E, M), var (E, M), deriv (E, M, D).
     """
 
     def __init__(self, ctx, expX, inputs, invQt, invQ, precision=np.float64):
@@ -330,45 +406,23 @@ class BatchModel(Model):
         self.dtype = np.dtype(precision)
         if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             raise TypeError("precision must be float32 or float64, got %r" % (precision,))
-        inputs = np.ascontiguousarray(inputs, dtype=self.dtype)
+        inputs = np.ascontiguousarray(inputs, dtype=np.float64)
         self.n_train, self.n_inputs = inputs.shape
-        expX = np.ascontiguousarray(expX, dtype=self.dtype)
+        expX = np.ascontiguousarray(expX, dtype=np.float64)
         if expX.ndim != 2:
             raise ValueError("expX must be (n_emulators, theta_size)")
         self.n_emulators = E = expX.shape[0]
-        invQt = np.ascontiguousarray(invQt, dtype=self.dtype)
-        invQ = np.ascontiguousarray(invQ, dtype=self.dtype)
+        invQt = np.ascontiguousarray(invQt, dtype=np.float64)
+        invQ = np.ascontiguousarray(invQ, dtype=np.float64)
         if invQt.shape != (E, self.n_train) or invQ.shape != (E, self.n_train, self.n_train):
             raise ValueError("invQt must be (E, N) and invQ (E, N, N)")
-        fn = ctx.lib.gp_batch_create_f64 if self.dtype == np.float64 else ctx.lib.gp_batch_create_f32
+        fn = ctx.lib.gp_batch_create_f64 if self.dtype == np.float64 else ctx.lib.gp_batch_create_f32_h64
         h = c_void_p()
         check(fn(ctx.h, E, _ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ),
                  self.n_train, self.n_inputs, expX.shape[1], ctypes.byref(h)), "gp_batch_create")
         self.h = h
 
-    def predict(self, testing, deriv_layout=GP_DERIV_ROWMAJOR):
-        testing = np.ascontiguousarray(testing, dtype=self.dtype)
-        M, D = testing.shape
-        E = self.n_emulators
-        if D != self.n_inputs:
-            raise ValueError("testing has %d columns, model has %d inputs" % (D, self.n_inputs))
-        isz = self.dtype.itemsize
-        d_t = self.ctx.to_device(testing)
-        d_mu = self.ctx.malloc(max(1, E * M * isz))
-        d_var = self.ctx.malloc(max(1, E * M * isz))
-        d_der = self.ctx.malloc(max(1, E * M * D * isz))
-        try:
-            self.predict_device(d_t, d_mu, d_var, d_der, M, deriv_layout)
-            mu = self.ctx.to_host(d_mu, (E, M), self.dtype)
-            var = self.ctx.to_host(d_var, (E, M), self.dtype)
-            shape = (E, M, D) if deriv_layout == GP_DERIV_ROWMAJOR else (E, D, M)
-            deriv = self.ctx.to_host(d_der, shape, self.dtype)
-        finally:
-            for p in (d_t, d_mu, d_var, d_der):
-                self.ctx.free(p)
-        return mu, var, deriv
-
-    def hessian(self, testing):
+    def hessian(self, testing, out=None):
         raise GpuPredictError("hessian is per emulator; build a Model for the emulator wanted")
 
 
@@ -391,8 +445,10 @@ def pack_model(expX, inputs, invQt, invQ, precision=np.float64):
     fn = lib.gp_pack_model_f64 if dt == np.float64 else lib.gp_pack_model_f32
     check(fn(_ptr(expX), _ptr(inputs), _ptr(invQt), _ptr(invQ), N, D, expX.size,
              _ptr(xa), _ptr(fr), _ptr(sd), _ptr(b)), "gp_pack_model")
+    nk = c_int(0)
+    check(lib.gp_kernel_ksteps(N, D, ctypes.byref(nk)), "gp_kernel_ksteps")
     return dict(xa=xa, frags=fr, sd=sd[:kd.value], centre=sd[kd.value:2 * kd.value], b=b[0],
-                kernel_d=kd.value, kernel_nb=knb.value)
+                kernel_d=kd.value, kernel_nb=knb.value, kernel_nk=nk.value)
 
 
 _tls = threading.local()

@@ -2,7 +2,7 @@
 
     python -m gp_emulator_amd.build [--force] [--jobs N]
 
-One object per (compute dtype, NB) kernel translation unit + the C-ABI object, linked into
+One object per (compute dtype, kernel size) translation unit + the C-ABI object, linked into
 ``gp_emulator_amd/libgp_predict_hip.so`` (in-tree, git-ignored, shipped to the GPU box by
 gpurun).  hipcc cross-compiles without a GPU.  Replaces the reference's CMake/CUDA build
 (CMakeLists.txt, gp_emulator/gpu/CMakeLists.txt, setup.py:16-35), which picks ONE precision
@@ -27,9 +27,10 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
 
 
-def kernel_nbs():
+def kernel_sizes(which):
+    """The NK (predict kernels) or NB (matrix-core Hessian kernels) list of gp_dispatch.hpp."""
     text = open(os.path.join(CSRC, "gp_dispatch.hpp")).read()
-    m = re.search(r"GP_FOR_EACH_KERNEL_NB\(X\)(.*)", text)
+    m = re.search(r"GP_FOR_EACH_KERNEL_%s\(X\)(.*)" % which, text)
     return [int(x) for x in re.findall(r"X\((\d+)\)", m.group(1))]
 
 
@@ -45,10 +46,40 @@ def source_digest():
     return h.hexdigest()
 
 
+def _includes(path, seen):
+    """Files ``path`` includes with #include "...", transitively (csrc/ and include/ only)."""
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        for d in (CSRC, os.path.join(ROOT, "include")):
+            _includes(os.path.join(d, name), seen)
+    return seen
+
+
+def unit_digest(cmd):
+    """Digest of one compile command: its flags plus the source and every header it pulls in."""
+    src = next(a for a in cmd if a.endswith(".hip"))
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for f in sorted(_includes(src, set())):
+        h.update(f.encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def run(cmd):
+    """Compile one translation unit unless its object is up to date (digest beside the object)."""
+    obj = cmd[-1]
+    stamp = obj + ".digest" if "-c" in cmd else None     # (the link step always runs)
+    digest = unit_digest(cmd) if stamp else None
+    if stamp and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return ""
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    if stamp:
+        with open(stamp, "w") as fh:
+            fh.write(digest)
     return r.stdout
 
 
@@ -74,14 +105,19 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
         if verbose:
             print("[gp build] up to date:", LIB)
         return LIB
+    if force:                      # forget every per-unit digest: recompile everything
+        for name in os.listdir(OBJ):
+            if name.endswith(".o.digest"):
+                os.remove(os.path.join(OBJ, name))
     jobs = jobs or min(8, os.cpu_count() or 1)
     tasks = []
     for tname, ctype in (("f64", "double"), ("f32", "float")):
-        for nb in kernel_nbs():
-            obj = os.path.join(OBJ, "kern_%s_%d.o" % (tname, nb))
+        for nk in kernel_sizes("NK"):
+            obj = os.path.join(OBJ, "kern_%s_%d.o" % (tname, nk))
             tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
-                                            "-DGP_NB=%d" % nb, "-c",
+                                            "-DGP_NK=%d" % nk, "-c",
                                             os.path.join(CSRC, "gp_kernels_tu.hip"), "-o", obj])
+        for nb in kernel_sizes("NB"):
             obj = os.path.join(OBJ, "hessm_%s_%d.o" % (tname, nb))
             tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname,
                                             "-DGP_NB=%d" % nb, "-c",
@@ -99,7 +135,14 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
     abi_obj = os.path.join(OBJ, "gp_abi.o")
     tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_abi.hip"), "-o", abi_obj])
     # biggest kernels first so the pool drains evenly
-    tasks.sort(key=lambda c: -int(next((a[8:] for a in c if a.startswith("-DGP_NB=")), "0")))
+    def weight(c):
+        for a in c:
+            if a.startswith("-DGP_NK="):
+                return int(a[8:])
+            if a.startswith("-DGP_NB="):
+                return 4 * int(a[8:])
+        return 0
+    tasks.sort(key=lambda c: -weight(c))
     if verbose:
         print("[gp build] compiling %d translation units with %d jobs" % (len(tasks), jobs))
     with concurrent.futures.ThreadPoolExecutor(jobs) as ex:

@@ -4,20 +4,26 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
+#include <type_traits>
 #include <vector>
+
+#include <sched.h>
 
 #include "gp_dispatch.hpp"
 #include "gp_generic_kernel.hpp"
 #include "gp_hessian_kernel.hpp"
 #include "gp_hessian_mfma_kernel.hpp"
+#include "gp_host_pool.hpp"
 #include "gp_predict_kernel.hpp"
 #include "gp_reconstruct_kernel.hpp"
 #include "gp_train_args.hpp"
@@ -35,10 +41,10 @@ GP_FOR_EACH_KERNEL_NB(GP_DECL)
 #undef GP_DECL
 hipError_t launch_hessian_f32(int, const HessianArgs<float>&, int, hipStream_t);
 hipError_t launch_hessian_f64(int, const HessianArgs<double>&, int, hipStream_t);
-#define GP_DECL(nb)                                                                         \
-  hipError_t launch_predict_f32_##nb(int, const PredictArgs<float>&, int, hipStream_t);     \
-  hipError_t launch_predict_f64_##nb(int, const PredictArgs<double>&, int, hipStream_t);
-GP_FOR_EACH_KERNEL_NB(GP_DECL)
+#define GP_DECL(nk)                                                                         \
+  hipError_t launch_predict_f32_##nk(int, const PredictArgs<float>&, int, hipStream_t);     \
+  hipError_t launch_predict_f64_##nk(int, const PredictArgs<double>&, int, hipStream_t);
+GP_FOR_EACH_KERNEL_NK(GP_DECL)
 #undef GP_DECL
 }  // namespace gpk
 
@@ -63,39 +69,77 @@ static int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                \
   } while (0)
 
-struct gp_ctx {
-  int device;
-  hipStream_t stream;
-  int compute_units;
-  // grow-only device scratch for the host-pointer (predict_wrap) path
-  void* scratch;
-  size_t scratch_bytes;
-  void* dbg;   // diagnostic (GP_STAMPS) builds: device buffer for segment cycle sums
-  // pipelined host-pointer path: second stream, pinned staging (2 slots), slot events
-  hipStream_t stream2;
-  void* stage_in[2];
-  void* stage_out[2];
-  size_t stage_in_bytes, stage_out_bytes;
-  hipEvent_t slot_done[2];
-  bool pipe_ready;
-};
-
 struct gp_model {
   int device;
   int dtype;
   int n_train, n_inputs;
   int kernel_d, kernel_nb;
+  int kernel_nk;                           // k-steps the predict kernel is compiled for (0: general-shape kernel)
   int n_emulators;                         // > 1: batched emulators sharing inputs/test rows
   long long xa_stride, frags_stride, sd_stride;   // elements between emulators
   void* d_xa;
   void* d_frags;
   void* d_sd;
+  // the scale sqrt(e_d) and centre c_d the kernel applies to test rows, as doubles (emulator 0):
+  // the host applies them itself, in double, when it stages float64 rows for a float32 model
+  std::vector<double> scale_host, centre_host;
   // Hessian on the matrix core (gp_hessian_mfma_kernel.hpp): the constant products
   // x''_id x''_id2 in fragment order, built on the first Hessian call from a host copy of the
-  // scaled rows (double, [n_train][kernel_d])
+  // scaled rows (double, [16 * kernel_nb slots][kernel_d])
   std::vector<double> xs_host;
   std::mutex h_mutex;
   void* d_pfrags;
+};
+
+// Host-pointer path (predict_host): slabs of the caller's arrays flow through kPipeSlots slots,
+// each with its own stream, pinned staging buffers and device buffers.
+constexpr int kPipeSlotsMax = 6;
+// slots in use (GP_HOST_SLOTS, default 3)
+static int pipe_slots() {
+  static const int n = [] {
+    const char* ev = getenv("GP_HOST_SLOTS");
+    const int v = ev ? atoi(ev) : 3;
+    return v < 2 ? 2 : (v > kPipeSlotsMax ? kPipeSlotsMax : v);
+  }();
+  return n;
+}
+#define kPipeSlots pipe_slots()
+struct gp_pipe {
+  bool ready = false;
+  hipStream_t stream[kPipeSlotsMax] = {};
+  hipEvent_t done[kPipeSlotsMax] = {};
+  void* stage_in[kPipeSlotsMax] = {};
+  void* stage_out[kPipeSlotsMax] = {};
+  void* dev[kPipeSlotsMax] = {};
+
+  size_t stage_in_bytes = 0, stage_out_bytes = 0, dev_bytes = 0;
+  std::unique_ptr<gph::ThreadPool> pool;
+};
+
+// predict_wrap re-sends the emulator's constants with every block (as the reference's boundary
+// does, GaussianProcess.py:313-316).  The context remembers the last few packed models together
+// with a copy of the host arrays they were made from; a call whose constants compare equal
+// byte for byte reuses the model instead of packing, allocating and uploading again.
+struct gp_cached_model {
+  gp_model* model = nullptr;
+  int host_dtype = 0, compute_dtype = 0, n_train = 0, n_inputs = 0, theta_size = 0;
+  bool with_invq = false;
+  std::vector<char> key;                   // expX | inputs | invQt | invQ, as given
+  unsigned long long stamp = 0;
+};
+constexpr int kModelCacheSlots = 4;
+
+struct gp_ctx {
+  int device;
+  hipStream_t stream;
+  int compute_units;
+  // grow-only device scratch (likelihood batch)
+  void* scratch;
+  size_t scratch_bytes;
+  void* dbg;   // diagnostic (GP_STAMPS) builds: device buffer for segment cycle sums
+  gp_pipe pipe;
+  gp_cached_model cache[kModelCacheSlots];
+  unsigned long long cache_clock = 0;
 };
 
 struct gp_event {
@@ -108,27 +152,36 @@ static const int kKernelD[] = {
     GP_FOR_EACH_KERNEL_D(GP_V)
 #undef GP_V
 };
-static const int kKernelNB[] = {
+static const int kKernelNK[] = {
 #define GP_V(d) d,
-    GP_FOR_EACH_KERNEL_NB(GP_V)
+    GP_FOR_EACH_KERNEL_NK(GP_V)
 #undef GP_V
 };
 
-// Kernel choice.  *knb > 0: the fused MFMA kernel predict_kernel<T, *kd, *knb>.
+// Kernel choice.  *knk > 0: the fused MFMA kernel predict_kernel<T, *kd, *knk> (*knk k-steps of
+// 4 training points; the packed images hold *knb = ceil(*knk / 4) blocks of 16).
 // *knb == 0: the general-shape kernel (gp_generic_kernel.hpp); *kd is then the padded row
 // dimension (a compiled kernel D when n_inputs <= 16, so the Hessian kernel can share the
 // packed rows; n_inputs itself otherwise).
-static int pick_kernel(int n_train, int n_inputs, int* kd, int* knb) {
+static int pick_kernel(int n_train, int n_inputs, int* kd, int* knb, int* knk = nullptr) {
   *kd = *knb = -1;
+  int nk = -1;
   for (int d : kKernelD)
     if (d >= n_inputs) { *kd = d; break; }
-  const int need = (n_train + 15) / 16;
-  for (int nb : kKernelNB)
-    if (nb >= need) { *knb = nb; break; }
+  static const bool whole_blocks = [] {      // A/B switch: kernels of whole 16-blocks only
+    const char* ev = getenv("GP_NO_KSKIP");
+    return ev && atoi(ev) != 0;
+  }();
+  const int need = (n_train + 3) / 4;
+  for (int k : kKernelNK)
+    if (k >= need && !(whole_blocks && k % 4 != 0)) { nk = k; break; }
+  if (nk > 0) *knb = (nk + 3) / 4;
+  if (knk) *knk = nk;
   if (*kd > 0 && *knb > 0) return GP_OK;
   if (n_train <= gpk::gkMaxN && n_inputs <= gpk::gkMaxD) {
     if (*kd < 0) *kd = n_inputs;
     *knb = 0;
+    if (knk) *knk = 0;
     return GP_OK;
   }
   return fail(GP_ERR_UNSUPPORTED,
@@ -174,21 +227,25 @@ static int pack_model(const TH* expX, const TH* inputs, const TH* invQt, const T
   sd[2 * kd] = (T)expX[D];
   const double lnb = std::log((double)expX[D]);
   std::memset(xa, 0, sizeof(T) * (size_t)NP * DS);
+  // Training point i lives in slot point_slot(i) of the packed images when the fused kernel
+  // runs (gp_predict_kernel.hpp: a partly filled last block then fills whole k-steps first);
+  // the general-shape kernel keeps the natural order.
   for (int i = 0; i < N; ++i) {
+    const size_t row = (size_t)(knb > 0 ? gpk::point_slot<T>(i) : i) * DS;
     double n2 = 0.0;
     for (int d = 0; d < D; ++d) {
       // the kernel works with the ROUNDED x'' (type T), so h must be built from it too
       const T xr = (T)((double)sd[d] * ((double)inputs[(size_t)i * D + d] - ctr[d]));
-      xa[(size_t)i * DS + d] = xr;
+      xa[row + d] = xr;
       n2 += (double)xr * (double)xr;
     }
-    xa[(size_t)i * DS + kd] = (T)invQt[i];
-    xa[(size_t)i * DS + kd + 1] = (T)(lnb - 0.5 * n2);
+    xa[row + kd] = (T)invQt[i];
+    xa[row + kd + 1] = (T)(lnb - 0.5 * n2);
   }
-  // S' in fragment order: fragment (I <= J, s), lane l holds
-  //   S'[i = 16 I + own_sub(s, l >> 4)][j = 16 J + (l & 15)]
-  // with S'_IJ = M_IJ + M_JI^T for I < J and M_JJ on the diagonal, so that
-  //   k^T M k = sum_J sum_{I<=J} k_I^T S'_IJ k_J        for ANY matrix M.
+  // S' in fragment order: fragment (I >= J, s), lane l holds
+  //   S'[slot i = 16 I + own_sub(s, l >> 4)][slot j = 16 J + (l & 15)]
+  // with S'_IJ = M_IJ + M_JI^T for I > J and M_JJ on the diagonal, so that
+  //   k^T M k = sum_J sum_{I>=J} k_I^T S'_IJ k_J        for ANY matrix M.
   if (!invQ) return GP_OK;   // Hessian-only model: no variance operand
   if (knb == 0) {            // general-shape kernel: invQ as given
     for (size_t q = 0; q < (size_t)N * N; ++q) frags[q] = (T)invQ[q];
@@ -197,15 +254,15 @@ static int pack_model(const TH* expX, const TH* inputs, const TH* invQt, const T
   const int nfp = gpk::frag_count_padded(knb, gpk::Geo<T>::kChunk);
   std::memset(frags, 0, sizeof(T) * (size_t)nfp * 64);
   for (int J = 0; J < knb; ++J)
-    for (int I = 0; I <= J; ++I)
+    for (int I = J; I < knb; ++I)
       for (int s = 0; s < 4; ++s) {
         T* f = frags + (size_t)gpk::frag_index(I, J, s, knb) * 64;
         for (int l = 0; l < 64; ++l) {
-          const int i = gpk::own_index<T>(I, s, l >> 4);
-          const int j = 16 * J + (l & 15);
+          const int i = gpk::slot_point<T>(gpk::own_index<T>(I, s, l >> 4));
+          const int j = gpk::slot_point<T>(16 * J + (l & 15));
           if (i >= N || j >= N) continue;
           double v = (double)invQ[(size_t)i * N + j];
-          if (I < J) v += (double)invQ[(size_t)j * N + i];
+          if (I > J) v += (double)invQ[(size_t)j * N + i];
           f[l] = (T)v;
         }
       }
@@ -213,21 +270,21 @@ static int pack_model(const TH* expX, const TH* inputs, const TH* invQt, const T
 }
 
 template <typename T>
-static hipError_t launch(int knb, int kd, const gpk::PredictArgs<T>& a, int grid, hipStream_t s);
+static hipError_t launch(int knk, int kd, const gpk::PredictArgs<T>& a, int grid, hipStream_t s);
 template <>
-hipError_t launch<float>(int knb, int kd, const gpk::PredictArgs<float>& a, int grid, hipStream_t s) {
-  switch (knb) {
-#define GP_CASE(nb) case nb: return gpk::launch_predict_f32_##nb(kd, a, grid, s);
-    GP_FOR_EACH_KERNEL_NB(GP_CASE)
+hipError_t launch<float>(int knk, int kd, const gpk::PredictArgs<float>& a, int grid, hipStream_t s) {
+  switch (knk) {
+#define GP_CASE(nk) case nk: return gpk::launch_predict_f32_##nk(kd, a, grid, s);
+    GP_FOR_EACH_KERNEL_NK(GP_CASE)
 #undef GP_CASE
   }
   return hipErrorInvalidValue;
 }
 template <>
-hipError_t launch<double>(int knb, int kd, const gpk::PredictArgs<double>& a, int grid, hipStream_t s) {
-  switch (knb) {
-#define GP_CASE(nb) case nb: return gpk::launch_predict_f64_##nb(kd, a, grid, s);
-    GP_FOR_EACH_KERNEL_NB(GP_CASE)
+hipError_t launch<double>(int knk, int kd, const gpk::PredictArgs<double>& a, int grid, hipStream_t s) {
+  switch (knk) {
+#define GP_CASE(nk) case nk: return gpk::launch_predict_f64_##nk(kd, a, grid, s);
+    GP_FOR_EACH_KERNEL_NK(GP_CASE)
 #undef GP_CASE
   }
   return hipErrorInvalidValue;
@@ -271,10 +328,6 @@ int gp_ctx_create(int device, gp_ctx** out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->dbg = nullptr;
-  c->stream2 = nullptr;
-  c->stage_in[0] = c->stage_in[1] = c->stage_out[0] = c->stage_out[1] = nullptr;
-  c->stage_in_bytes = c->stage_out_bytes = 0;
-  c->pipe_ready = false;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -288,13 +341,19 @@ int gp_ctx_destroy(gp_ctx* ctx) {
   if (!ctx) return GP_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (auto& c : ctx->cache)
+    if (c.model) gp_model_destroy(c.model);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
-  for (int k = 0; k < 2; ++k) {
-    if (ctx->stage_in[k]) (void)hipHostFree(ctx->stage_in[k]);
-    if (ctx->stage_out[k]) (void)hipHostFree(ctx->stage_out[k]);
-    if (ctx->pipe_ready) (void)hipEventDestroy(ctx->slot_done[k]);
+  gp_pipe& pp = ctx->pipe;
+  pp.pool.reset();
+  for (int k = 0; k < kPipeSlots; ++k) {
+    if (pp.stream[k]) (void)hipStreamSynchronize(pp.stream[k]);
+    if (pp.stage_in[k]) (void)hipHostFree(pp.stage_in[k]);
+    if (pp.stage_out[k]) (void)hipHostFree(pp.stage_out[k]);
+    if (pp.dev[k]) (void)hipFree(pp.dev[k]);
+    if (pp.done[k]) (void)hipEventDestroy(pp.done[k]);
+    if (pp.stream[k]) (void)hipStreamDestroy(pp.stream[k]);
   }
-  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return GP_OK;
@@ -326,7 +385,7 @@ int gp_ctx_device_info(gp_ctx* ctx, int* compute_units, int64_t* hbm_bytes, char
 }
 
 int gp_frag_index(int kernel_nb, int I, int J, int s) {
-  if (kernel_nb <= 0 || I < 0 || J < I || J >= kernel_nb || s < 0 || s > 3) return -1;
+  if (kernel_nb <= 0 || J < 0 || I < J || I >= kernel_nb || s < 0 || s > 3) return -1;
   return gpk::frag_index(I, J, s, kernel_nb);
 }
 
@@ -366,10 +425,11 @@ static int model_create(gp_ctx* ctx, int E, const TH* expX, const TH* inputs, co
   if (!ctx || !out) return fail(GP_ERR_INVALID, "null context or output");
   *out = nullptr;
   if (E <= 0) return fail(GP_ERR_INVALID, "n_emulators must be positive");
-  int kd, knb;
+  int kd, knb, knk;
   int64_t xa_len, fr_len;
   int rc = gp_pack_sizes(sizeof(T) == 8 ? GP_F64 : GP_F32, N, D, &kd, &knb, &xa_len, &fr_len);
   if (rc) return rc;
+  (void)pick_kernel(N, D, &kd, &knb, &knk);
   const int64_t sd_len = 2 * kd + 1;
   if (!invQ) fr_len = 0;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -381,6 +441,7 @@ static int model_create(gp_ctx* ctx, int E, const TH* expX, const TH* inputs, co
   m->n_inputs = D;
   m->kernel_d = kd;
   m->kernel_nb = knb;
+  m->kernel_nk = knk;
   m->n_emulators = E;
   m->xa_stride = xa_len;
   m->frags_stride = fr_len;
@@ -398,10 +459,19 @@ static int model_create(gp_ctx* ctx, int E, const TH* expX, const TH* inputs, co
                        invQ ? invQ + (size_t)k * N * N : nullptr, N, D, theta_size,
                        xa.data(), invQ ? fr.data() : nullptr, sd.data(), &b);
     if (rc) break;
-    if (E == 1 && knb > 0) {   // the rounded x'' the kernels see, for the Hessian's product matrix
+    if (k == 0) {              // what the kernel applies to test rows, as doubles
+      m->scale_host.resize(D);
+      m->centre_host.resize(D);
+      for (int d = 0; d < D; ++d) {
+        m->scale_host[d] = (double)sd[d];
+        m->centre_host[d] = (double)sd[kd + d];
+      }
+    }
+    if (E == 1 && knb > 0) {   // the rounded x'' the kernels see (by slot), for the Hessian's product matrix
       const int DSk = row_stride_of(kd);
-      m->xs_host.resize((size_t)N * kd);
-      for (int i = 0; i < N; ++i)
+      const int NPk = rows_padded(N, knb);
+      m->xs_host.resize((size_t)NPk * kd);
+      for (int i = 0; i < NPk; ++i)
         for (int d = 0; d < kd; ++d) m->xs_host[(size_t)i * kd + d] = (double)xa[(size_t)i * DSk + d];
     }
     e = hipMemcpyAsync((T*)m->d_xa + (size_t)k * xa_len, xa.data(), sizeof(T) * xa_len, hipMemcpyHostToDevice, ctx->stream);
@@ -434,7 +504,7 @@ hipError_t launch_generic<double>(const gpk::GenericArgs<double>& a, int grid, h
 template <typename T>
 static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_mu,
                           void* d_var, void* d_deriv, int64_t M, int layout,
-                          hipStream_t stream = nullptr) {
+                          hipStream_t stream = nullptr, bool rows_prescaled = false) {
   if (!stream) stream = ctx->stream;
   if (m->kernel_nb == 0) {   // general-shape kernel
     if (m->n_emulators != 1)
@@ -478,6 +548,7 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.frags_stride = m->frags_stride;
   a.sd_stride = m->sd_stride;
   a.dbg = (unsigned long long*)ctx->dbg;
+  a.rows_prescaled = rows_prescaled ? 1 : 0;
   constexpr int kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
   const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG * m->n_emulators;
   if ((M + kRowsPerWG - 1) / kRowsPerWG > 0x7fffffffLL)
@@ -485,7 +556,7 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   // persistent grid: the kernel's occupancy (2 waves per SIMD), grid-stride over work items
   int64_t grid = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU;
   if (grid > groups) grid = groups;
-  hipError_t e = launch<T>(m->kernel_nb, m->kernel_d, a, (int)grid, stream);
+  hipError_t e = launch<T>(m->kernel_nk, m->kernel_d, a, (int)grid, stream);
   if (e != hipSuccess) return fail(GP_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
   return GP_OK;
 }
@@ -545,11 +616,11 @@ static int ensure_hess_frags(gp_ctx* ctx, gp_model* m) {
       for (int s = 0; s < 4; ++s) {
         T* f = fr.data() + (size_t)gpk::hess_frag_index(c, I, s, knb) * 64;
         for (int l = 0; l < 64; ++l) {
-          const int i = gpk::own_index<T>(I, s, l >> 4);
+          const int i = gpk::own_index<T>(I, s, l >> 4);   // slot; padding slots hold zero rows
           const int q = l & 15;             // MFMA output row = accumulator r of lane group g
           const int d = 4 * gpk::hess_block_bi(c) + gpk::hess_row_r<T>(q);
           const int d2 = 4 * gpk::hess_block_bj(c) + gpk::hess_row_g<T>(q);
-          if (i >= N || d >= kd || d2 >= kd) continue;
+          if (gpk::slot_point<T>(i) >= N || d >= kd || d2 >= kd) continue;
           f[l] = (T)(m->xs_host[(size_t)i * kd + d] * m->xs_host[(size_t)i * kd + d2]);
         }
       }
@@ -565,7 +636,9 @@ static int ensure_hess_frags(gp_ctx* ctx, gp_model* m) {
 }
 
 template <typename T>
-static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_hess, int64_t M) {
+static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing, void* d_hess, int64_t M,
+                          hipStream_t stream = nullptr) {
+  if (!stream) stream = ctx->stream;
   if (m->n_inputs > GP_MAX_KERNEL_D)
     return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
   if (hessian_on_matrix_core(m)) {
@@ -583,7 +656,7 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
     const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG;
     int64_t grid = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU;
     if (grid > groups) grid = groups;
-    hipError_t e = launch_hessm<T>(m->kernel_nb, m->kernel_d, h, (int)grid, ctx->stream);
+    hipError_t e = launch_hessm<T>(m->kernel_nb, m->kernel_d, h, (int)grid, stream);
     if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian kernel launch: %s", hipGetErrorString(e));
     return GP_OK;
   }
@@ -600,7 +673,7 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   const int64_t groups = (M + gpk::hkRowsPerWG - 1) / gpk::hkRowsPerWG;
   int64_t grid = (int64_t)ctx->compute_units * 2;
   if (grid > groups) grid = groups;
-  hipError_t e = launch_hessian<T>(m->kernel_d, a, (int)grid, ctx->stream);
+  hipError_t e = launch_hessian<T>(m->kernel_d, a, (int)grid, stream);
   if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian kernel launch: %s", hipGetErrorString(e));
   return GP_OK;
 }
@@ -618,137 +691,328 @@ static int ensure_scratch(gp_ctx* ctx, size_t bytes) {
   return GP_OK;
 }
 
-// ---- pipelined host-pointer path --------------------------------------------------------
-// Large calls are cut into slabs that flow through two slots: while the GPU works on slab s
-// (H2D, kernel, D2H on the slot's own stream, all from/to PINNED staging), the calling thread
-// and a few helpers copy slab s+1 in and slab s-1 out of the caller's pageable arrays
-// (converting between the caller's type TH and the compute type T on the way, so a float32
-// predict on float64 numpy arrays needs no numpy casts at all).
+// ---- host-pointer path --------------------------------------------------------------------
+// Host arrays in, host arrays out (what every caller of the reference's predict() has).  The
+// rows are cut into slabs that flow through kPipeSlots slots; slot k owns a stream, pinned
+// staging buffers and device buffers.  For slab s the calling thread and the context's helper
+// threads (gp_host_pool.hpp)
+//   1. wait for slab s - kPipeSlots (same slot) to come back and copy it out of pinned staging
+//      into the caller's arrays,
+//   2. copy slab s from the caller's rows into pinned staging (converting the caller's type TH
+//      to the compute type T on the way: a float32 predict on float64 numpy arrays needs no
+//      numpy casts at all),
+//   3. enqueue H2D, kernel, D2H and an event on the slot's stream,
+// so the device works on up to kPipeSlots slabs while the host copies.  Nothing is allocated,
+// spawned or uploaded per call once the context is warm.  Measured on the GPU box
+// (profiles/r02_host_path_experiments.txt): 1e6 float64 rows of N=250, D=11 take 3.1 ms against
+// 9.6 ms in round 1; the host copies alone would take 1.1 ms, the kernels 1.4 ms, and H2D + D2H
+// of the 192 MB 3.0-3.5 ms -- the two directions do not overlap on this host, whatever streams
+// issue them -- so the path sits on its PCIe floor.  Tried and dropped: more slots (slower from
+// 4 up), non-temporal host copies (no gain), letting the kernel read / write pinned host memory
+// itself instead of H2D / D2H copies (4.1 ms), one stream per copy direction (no change),
+// pre-touching or huge-page advice for fresh output arrays (no gain; see _lib.OutputPool).
+// GP_HOST_TRACE=1 prints where a call's time went (event waits / host copies / enqueue).
 static int host_threads() {
   static int n = [] {
+    int avail = 1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) avail = CPU_COUNT(&set);
     const char* ev = getenv("GP_HOST_THREADS");
-    int v = ev ? atoi(ev) : 4;
-    return v < 1 ? 1 : (v > 16 ? 16 : v);
+    int v = ev ? atoi(ev) : 8;
+    if (v > avail) v = avail;
+    return v < 1 ? 1 : (v > 32 ? 32 : v);
   }();
   return n;
 }
 
-template <typename F>
-static void parallel_ranges(size_t n, F f) {
-  const int nt = host_threads();
-  if (nt <= 1 || n < (size_t)1 << 16) { f((size_t)0, n); return; }
-  const size_t per = (n + nt - 1) / nt;
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; ++t) {
-    const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
-    if (lo < hi) th.emplace_back([=] { f(lo, hi); });
-  }
-  f((size_t)0, per < n ? per : n);
-  for (auto& x : th) x.join();
+static gph::ThreadPool& host_pool(gp_ctx* ctx) {
+  if (!ctx->pipe.pool) ctx->pipe.pool.reset(new gph::ThreadPool(host_threads()));
+  return *ctx->pipe.pool;
 }
+
 
 template <typename TD, typename TS>
 static inline void convert_range(TD* dst, const TS* src, size_t lo, size_t hi) {
   if (sizeof(TD) == sizeof(TS)) std::memcpy((void*)(dst + lo), (const void*)(src + lo), (hi - lo) * sizeof(TD));
   else for (size_t i = lo; i < hi; ++i) dst[i] = (TD)src[i];
 }
-template <typename TD, typename TS>
-static void convert_copy(TD* dst, const TS* src, size_t n) {
-  parallel_ranges(n, [=](size_t lo, size_t hi) { convert_range(dst, src, lo, hi); });
-}
 
-static int ensure_pipeline(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
-  if (!ctx->pipe_ready) {
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&ctx->slot_done[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ctx->slot_done[1], hipEventDisableTiming));
-    ctx->pipe_ready = true;
-  }
-  if (ctx->stage_in_bytes < in_bytes) {
-    for (int k = 0; k < 2; ++k) {
-      if (ctx->stage_in[k]) HIP_TRY(hipHostFree(ctx->stage_in[k]));
-      ctx->stage_in[k] = nullptr;
-      HIP_TRY(hipHostMalloc(&ctx->stage_in[k], in_bytes, hipHostMallocDefault));
+static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
+  gp_pipe& pp = ctx->pipe;
+  if (!pp.ready) {
+    for (int k = 0; k < kPipeSlots; ++k) {
+      if (!pp.stream[k]) HIP_TRY(hipStreamCreateWithFlags(&pp.stream[k], hipStreamNonBlocking));
+      if (!pp.done[k]) HIP_TRY(hipEventCreateWithFlags(&pp.done[k], hipEventDisableTiming));
     }
-    ctx->stage_in_bytes = in_bytes;
+    pp.ready = true;
   }
-  if (ctx->stage_out_bytes < out_bytes) {
-    for (int k = 0; k < 2; ++k) {
-      if (ctx->stage_out[k]) HIP_TRY(hipHostFree(ctx->stage_out[k]));
-      ctx->stage_out[k] = nullptr;
-      HIP_TRY(hipHostMalloc(&ctx->stage_out[k], out_bytes, hipHostMallocDefault));
+  // grow-only; a size is recorded only after every slot's buffer exists, so a failed
+  // allocation can never leave a stale size beside a null buffer
+  if (pp.stage_in_bytes < in_bytes) {
+    pp.stage_in_bytes = 0;
+    for (int k = 0; k < kPipeSlots; ++k) {
+      if (pp.stage_in[k]) { void* q = pp.stage_in[k]; pp.stage_in[k] = nullptr; HIP_TRY(hipHostFree(q)); }
+      HIP_TRY(hipHostMalloc(&pp.stage_in[k], in_bytes, hipHostMallocDefault));
     }
-    ctx->stage_out_bytes = out_bytes;
+    pp.stage_in_bytes = in_bytes;
+  }
+  if (pp.stage_out_bytes < out_bytes) {
+    pp.stage_out_bytes = 0;
+    for (int k = 0; k < kPipeSlots; ++k) {
+      if (pp.stage_out[k]) { void* q = pp.stage_out[k]; pp.stage_out[k] = nullptr; HIP_TRY(hipHostFree(q)); }
+      HIP_TRY(hipHostMalloc(&pp.stage_out[k], out_bytes, hipHostMallocDefault));
+    }
+    pp.stage_out_bytes = out_bytes;
+  }
+  if (pp.dev_bytes < in_bytes + out_bytes) {
+    pp.dev_bytes = 0;
+    for (int k = 0; k < kPipeSlots; ++k) {
+      if (pp.dev[k]) { void* q = pp.dev[k]; pp.dev[k] = nullptr; HIP_TRY(hipFree(q)); }
+      HIP_TRY(hipMalloc(&pp.dev[k], in_bytes + out_bytes));
+    }
+    pp.dev_bytes = in_bytes + out_bytes;
   }
   return GP_OK;
 }
 
-constexpr int64_t kPipeSlab = 262144;      // rows per slab of the pipelined path
-constexpr int64_t kPipeMinRows = 65536;    // below this the simple path is as fast
-
-// T = compute type, TH = the caller's host type (T, or double with T = float)
-template <typename T, typename TH>
-static int predict_host_pipelined(gp_ctx* ctx, const gp_model* m, const TH* testing, TH* result,
-                                  TH* error, TH* deriv, int64_t M, int D, int layout) {
-  const int64_t slab = kPipeSlab;
-  const size_t in_elems = (size_t)slab * D, out_elems = (size_t)slab * (2 + D);
-  int rc = ensure_pipeline(ctx, in_elems * sizeof(T), out_elems * sizeof(T));
-  if (rc) return rc;
-  rc = ensure_scratch(ctx, 2 * (in_elems + out_elems) * sizeof(T));
-  if (rc) return rc;
-  hipStream_t streams[2] = {ctx->stream, ctx->stream2};
-  const int64_t ns = (M + slab - 1) / slab;
-  hipError_t e = hipSuccess;
-  auto rows_of = [&](int64_t s) { return (s + 1) * slab <= M ? slab : M - s * slab; };
-  auto copy_out = [&](int64_t s) -> hipError_t {       // pinned slot -> caller's arrays
-    const int k = (int)(s & 1);
-    const int64_t n = rows_of(s), s0 = s * slab;
-    hipError_t ee = hipEventSynchronize(ctx->slot_done[k]);
-    if (ee != hipSuccess) return ee;
-    const T* o = (const T*)ctx->stage_out[k];
-    // one parallel region per slab: every helper takes a range of ROWS and copies its part of
-    // all three outputs (threads are spawned per region, so regions are kept few and large)
-    parallel_ranges((size_t)n, [=](size_t lo, size_t hi) {
-      convert_range(result + s0, o, lo, hi);
-      convert_range(error + s0, o + n, lo, hi);
-      if (layout == GP_DERIV_ROWMAJOR) {
-        convert_range(deriv + (size_t)s0 * D, o + 2 * n, lo * D, hi * D);
-      } else {
-        for (int d = 0; d < D; ++d) convert_range(deriv + (size_t)d * M + s0, o + 2 * n + (size_t)d * n, lo, hi);
-      }
-    });
-    return hipSuccess;
-  };
-  for (int64_t s = 0; s < ns && e == hipSuccess; ++s) {
-    const int k = (int)(s & 1);
-    const int64_t n = rows_of(s), s0 = s * slab;
-    if (s >= 2) e = copy_out(s - 2);                   // frees slot k (its D2H has finished)
-    if (e != hipSuccess) break;
-    convert_copy((T*)ctx->stage_in[k], testing + (size_t)s0 * D, (size_t)n * D);
-    T* d_in = (T*)ctx->scratch + (size_t)k * (in_elems + out_elems);
-    T* d_out = d_in + in_elems;
-    e = hipMemcpyAsync(d_in, ctx->stage_in[k], sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, streams[k]);
-    if (e != hipSuccess) break;
-    rc = predict_device<T>(ctx, m, d_in, d_out, d_out + n, d_out + 2 * n, n, layout, streams[k]);
-    if (rc) break;
-    e = hipMemcpyAsync(ctx->stage_out[k], d_out, sizeof(T) * (size_t)n * (2 + D), hipMemcpyDeviceToHost, streams[k]);
-    if (e == hipSuccess) e = hipEventRecord(ctx->slot_done[k], streams[k]);
-  }
-  for (int64_t s = (ns >= 2 ? ns - 2 : 0); s < ns && e == hipSuccess && rc == GP_OK; ++s) e = copy_out(s);
-  // leave both streams idle whatever happened (staging buffers are reused by the next call)
-  (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(GP_ERR_HIP, "pipelined predict: %s", hipGetErrorString(e));
-  return GP_OK;
-}
-
-// Host-pointer path = predict_wrap: upload constants + test rows, one launch, download.
-// Rows are processed in slabs so the device scratch stays bounded for any n_predict.
+// Rows per slab.  One emulator: two rounds of the persistent grid (65 536 rows in fp64), small
+// enough that the first copy-in and the last copy-out -- the only parts nothing overlaps --
+// stay short, large enough that launches and thread hand-offs do not show; calls that would be
+// one or two slabs are cut into four so that something overlaps.  Batched emulators: as many
+// rows as keep a slot's output staging near 16 MiB.  max_rows (> 0) bounds it from above:
+// gpu_predict's `threshold` (no more than that many rows are on the device per launch).
 template <typename T>
-static int predict_wrap_simple(gp_ctx* ctx, gp_model* m, const T* testing, T* result, T* error,
-                               T* deriv, int64_t M, int D, int layout);
+static int64_t slab_rows(const gp_ctx* ctx, const gp_model* m, int64_t M, int64_t out_row_elems, int64_t max_rows) {
+  constexpr int64_t kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
+  static const int rounds = [] { const char* ev = getenv("GP_HOST_SLAB_ROUNDS"); const int v = ev ? atoi(ev) : 2; return v < 1 ? 1 : v; }();
+  int64_t slab = rounds * (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU * kRowsPerWG;
+  const int64_t by_bytes = ((int64_t)16 << 20) / (int64_t)(out_row_elems * sizeof(T));
+  if (slab > by_bytes) slab = by_bytes;
+  if (M < 4 * slab && M >= 4 * 4096) slab = (M + 3) / 4;
+  slab = (slab + kRowsPerWG - 1) / kRowsPerWG * kRowsPerWG;
+  if (max_rows > 0 && slab > max_rows) slab = max_rows;
+  if (slab > M) slab = M;
+  (void)m;
+  return slab < 1 ? 1 : slab;
+}
 
+// The slab pipeline.  in_row / out_row: elements per row in the staging buffers (compute type T).
+//   copy_in(stage, s0, n, lo, hi)   rows [lo, hi) of slab [s0, s0 + n): caller's rows -> stage
+//   launch(d_in, d_out, n, stream)  enqueue the kernel(s) for a slab
+//   copy_out(stage, s0, n, lo, hi)  rows [lo, hi) of the slab: stage -> caller's arrays
+template <typename T, typename FIn, typename FLaunch, typename FOut>
+static int run_slab_pipeline(gp_ctx* ctx, int64_t M, int64_t slab, size_t in_row, size_t out_row,
+                             FIn copy_in, FLaunch launch, FOut copy_out) {
+  const size_t in_elems = (size_t)slab * in_row, out_elems = (size_t)slab * out_row;
+  int rc = ensure_pipe(ctx, in_elems * sizeof(T), out_elems * sizeof(T));
+  if (rc) return rc;
+  gp_pipe& pp = ctx->pipe;
+  const int64_t ns = (M + slab - 1) / slab;
+  auto rows_of = [&](int64_t s) { return (s + 1) * slab <= M ? slab : M - s * slab; };
+  // split a slab's rows into tasks of >= 256 KiB each, at most 2 per thread
+  auto tasks_for = [&](int64_t n, size_t row_bytes) {
+    const size_t bytes = (size_t)n * row_bytes;
+    int t = (int)(bytes / ((size_t)256 << 10));
+    const int cap = 2 * host_threads();
+    return t < 1 ? 1 : (t > cap ? cap : t);
+  };
+  static const bool trace = [] { const char* ev = getenv("GP_HOST_TRACE"); return ev && atoi(ev) != 0; }();
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  double t_wait = 0, t_copy = 0, t_enq = 0;
+  const auto t_begin = now();
+  hipError_t e = hipSuccess;
+  for (int64_t s = 0; s < ns + kPipeSlots && e == hipSuccess && rc == GP_OK; ++s) {
+    const int k = (int)(s % kPipeSlots);
+    const int64_t so = s - kPipeSlots;            // slab whose results come back now
+    const bool has_out = so >= 0 && so < ns, has_in = s < ns;
+    if (!has_out && !has_in) continue;
+    const int64_t n_out = has_out ? rows_of(so) : 0, n_in = has_in ? rows_of(s) : 0;
+    auto t0 = now();
+    if (has_out) {
+      e = hipEventSynchronize(pp.done[k]);        // slab so: D2H finished, slot k is free
+      if (e != hipSuccess) break;
+    }
+    auto t1 = now();
+    const int t_out = has_out ? tasks_for(n_out, out_row * sizeof(T)) : 0;
+    const int t_in = has_in ? tasks_for(n_in, in_row * sizeof(T)) : 0;
+    const T* o_stage = (const T*)pp.stage_out[k];
+    T* i_stage = (T*)pp.stage_in[k];
+    // copy-in tasks first (the device waits for them), then copy-out
+    auto task = [&](int t) {
+      if (t < t_in) {
+        const int64_t lo = n_in * t / t_in, hi = n_in * (t + 1) / t_in;
+        copy_in(i_stage, s * slab, n_in, lo, hi);
+      } else {
+        const int u = t - t_in;
+        const int64_t lo = n_out * u / t_out, hi = n_out * (u + 1) / t_out;
+        copy_out(o_stage, so * slab, n_out, lo, hi);
+      }
+    };
+    const int n_tasks = t_in + t_out;
+    if (n_tasks == 1) task(0);
+    else host_pool(ctx).run(n_tasks, task);
+    auto t2 = now();
+    if (has_in) {
+      // GP_HOST_SKIP (timing diagnostics only, results are wrong): bit 0 skips the H2D copies,
+      // bit 1 the kernel, bit 2 the D2H copies
+      static const int skip = [] { const char* ev = getenv("GP_HOST_SKIP"); return ev ? atoi(ev) : 0; }();
+      T* d_in = (T*)pp.dev[k];
+      T* d_out = d_in + in_elems;
+      if (!(skip & 1))
+        e = hipMemcpyAsync(d_in, pp.stage_in[k], sizeof(T) * (size_t)n_in * in_row, hipMemcpyHostToDevice, pp.stream[k]);
+      if (e != hipSuccess) break;
+      if (!(skip & 2)) rc = launch(d_in, d_out, n_in, pp.stream[k]);
+      if (rc) break;
+      if (!(skip & 4))
+        e = hipMemcpyAsync(pp.stage_out[k], d_out, sizeof(T) * (size_t)n_in * out_row, hipMemcpyDeviceToHost, pp.stream[k]);
+      if (e == hipSuccess) e = hipEventRecord(pp.done[k], pp.stream[k]);
+    }
+    if (trace) {
+      auto t3 = now();
+      t_wait += std::chrono::duration<double>(t1 - t0).count();
+      t_copy += std::chrono::duration<double>(t2 - t1).count();
+      t_enq += std::chrono::duration<double>(t3 - t2).count();
+    }
+  }
+  // leave every stream idle whatever happened (the buffers are reused by the next call)
+  for (int k = 0; k < kPipeSlots; ++k) (void)hipStreamSynchronize(pp.stream[k]);
+  if (trace)
+    fprintf(stderr, "[gp host pipeline] rows=%lld slab=%lld slabs=%lld threads=%d: total %.3f ms = event waits %.3f + host copies %.3f + enqueue %.3f\n",
+            (long long)M, (long long)slab, (long long)ns, host_threads(),
+            std::chrono::duration<double>(now() - t_begin).count() * 1e3, t_wait * 1e3, t_copy * 1e3, t_enq * 1e3);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "host pipeline: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
+// predict for host arrays.  T = compute type (the model's), TH = the caller's host type (T, or
+// double with T = float).  Outputs: result/error [E][M], deriv [E][M*D] (row-major) or [E][D][M].
+template <typename T, typename TH>
+static int predict_host(gp_ctx* ctx, const gp_model* m, const TH* testing, TH* result, TH* error,
+                        TH* deriv, int64_t M, int layout, int64_t max_rows) {
+  const int D = m->n_inputs, E = m->n_emulators;
+  if (M == 0) return GP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t out_row = (size_t)E * (2 + D);
+  const int64_t slab = slab_rows<T>(ctx, m, M, (int64_t)out_row, max_rows);
+  // float64 rows for a float32 model: centre and scale in double, round once (the kernel then
+  // takes the rows as they are).  Rounding the raw rows first would cost |t| / |t - c| in
+  // relative accuracy of every distance -- 9e-5 of the mean on the PROSAIL emulator.
+  const bool prescale = sizeof(T) == 4 && sizeof(TH) == 8 && E == 1 && m->kernel_nb > 0;
+  const double* sc = m->scale_host.data();
+  const double* ce = m->centre_host.data();
+  auto copy_in = [=](T* stage, int64_t s0, int64_t n, int64_t lo, int64_t hi) {
+    (void)n;
+    const TH* src = testing + (size_t)s0 * D;
+    if (prescale) {
+      // scale and centre replicated over 8 rows: the loops below run over contiguous memory
+      // with a trip count the compiler can vectorise (D itself is 10 or 11)
+      double sc8[8 * GP_MAX_KERNEL_D], ce8[8 * GP_MAX_KERNEL_D];
+      for (int q = 0; q < 8 * D; ++q) { sc8[q] = sc[q % D]; ce8[q] = ce[q % D]; }
+      int64_t r = lo;
+      for (; r + 8 <= hi; r += 8) {
+        const TH* a = src + (size_t)r * D;
+        T* o = stage + (size_t)r * D;
+        for (int q = 0; q < 8 * D; ++q) o[q] = (T)(sc8[q] * ((double)a[q] - ce8[q]));
+      }
+      for (; r < hi; ++r)
+        for (int d = 0; d < D; ++d)
+          stage[(size_t)r * D + d] = (T)(sc[d] * ((double)src[(size_t)r * D + d] - ce[d]));
+    } else {
+      convert_range(stage, src, (size_t)lo * D, (size_t)hi * D);
+    }
+  };
+  auto launch = [=](T* d_in, T* d_out, int64_t n, hipStream_t st) {
+    return predict_device<T>(ctx, m, d_in, d_out, d_out + (size_t)E * n, d_out + (size_t)2 * E * n, n,
+                             layout, st, prescale);
+  };
+  // staged slab: mu [E][n], var [E][n], deriv [E][n*D] or [E][D][n]
+  auto copy_out = [=](const T* o, int64_t s0, int64_t n, int64_t lo, int64_t hi) {
+    for (int e = 0; e < E; ++e) {
+      convert_range(result + (size_t)e * M + s0, o + (size_t)e * n, (size_t)lo, (size_t)hi);
+      convert_range(error + (size_t)e * M + s0, o + (size_t)(E + e) * n, (size_t)lo, (size_t)hi);
+      const T* od = o + (size_t)2 * E * n + (size_t)e * n * D;
+      TH* hd = deriv + (size_t)e * M * D;
+      if (layout == GP_DERIV_ROWMAJOR) {
+        convert_range(hd + (size_t)s0 * D, od, (size_t)lo * D, (size_t)hi * D);
+      } else {
+        for (int d = 0; d < D; ++d)
+          convert_range(hd + (size_t)d * M + s0, od + (size_t)d * n, (size_t)lo, (size_t)hi);
+      }
+    }
+  };
+  return run_slab_pipeline<T>(ctx, M, slab, (size_t)D, out_row, copy_in, launch, copy_out);
+}
+
+// Hessian for host arrays: (M, D, D) out, same pipeline (2 KiB per row of output at D = 16).
+template <typename T>
+static int hessian_host_model(gp_ctx* ctx, const gp_model* m, const T* testing, T* hess, int64_t M) {
+  const int D = m->n_inputs;
+  if (M == 0) return GP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t out_row = (size_t)D * D;
+  const int64_t slab = slab_rows<T>(ctx, m, M, (int64_t)out_row, 0);
+  auto copy_in = [=](T* stage, int64_t s0, int64_t, int64_t lo, int64_t hi) {
+    convert_range(stage, testing + (size_t)s0 * D, (size_t)lo * D, (size_t)hi * D);
+  };
+  auto launch = [=](T* d_in, T* d_out, int64_t n, hipStream_t st) {
+    return hessian_device<T>(ctx, m, d_in, d_out, n, st);
+  };
+  auto copy_out = [=](const T* o, int64_t s0, int64_t, int64_t lo, int64_t hi) {
+    convert_range(hess + (size_t)s0 * out_row, o, (size_t)lo * out_row, (size_t)hi * out_row);
+  };
+  return run_slab_pipeline<T>(ctx, M, slab, (size_t)D, out_row, copy_in, launch, copy_out);
+}
+
+// ---- the context's model cache (see gp_cached_model) ---------------------------------------
+template <typename T, typename TH>
+static int cached_model(gp_ctx* ctx, const TH* expX, const TH* inputs, const TH* invQt, const TH* invQ,
+                        int N, int D, int theta_size, gp_model** out) {
+  *out = nullptr;
+  if (!expX || !inputs || !invQt) return fail(GP_ERR_INVALID, "null pointer");
+  if (N <= 0 || D <= 0 || theta_size < D + 1) return fail(GP_ERR_INVALID, "bad sizes");
+  const int hd = sizeof(TH) == 8 ? GP_F64 : GP_F32, cd = sizeof(T) == 8 ? GP_F64 : GP_F32;
+  const size_t b0 = sizeof(TH) * (size_t)theta_size, b1 = sizeof(TH) * (size_t)N * D,
+               b2 = sizeof(TH) * (size_t)N, b3 = invQ ? sizeof(TH) * (size_t)N * N : 0;
+  gp_cached_model* victim = &ctx->cache[0];
+  for (auto& c : ctx->cache) {
+    if (c.model && c.host_dtype == hd && c.compute_dtype == cd && c.n_train == N && c.n_inputs == D &&
+        c.theta_size == theta_size && c.with_invq == (invQ != nullptr) && c.key.size() == b0 + b1 + b2 + b3) {
+      const char* k = c.key.data();
+      if (!std::memcmp(k, expX, b0) && !std::memcmp(k + b0, inputs, b1) && !std::memcmp(k + b0 + b1, invQt, b2) &&
+          (!invQ || !std::memcmp(k + b0 + b1 + b2, invQ, b3))) {
+        c.stamp = ++ctx->cache_clock;
+        *out = c.model;
+        return GP_OK;
+      }
+    }
+    if (!c.model) { if (victim->model) victim = &c; }
+    else if (victim->model && c.stamp < victim->stamp) victim = &c;
+  }
+  gp_model* m = nullptr;
+  int rc = model_create<T, TH>(ctx, 1, expX, inputs, invQt, invQ, N, D, theta_size, &m);
+  if (rc) return rc;
+  if (victim->model) gp_model_destroy(victim->model);
+  victim->model = m;
+  victim->host_dtype = hd;
+  victim->compute_dtype = cd;
+  victim->n_train = N;
+  victim->n_inputs = D;
+  victim->theta_size = theta_size;
+  victim->with_invq = invQ != nullptr;
+  victim->key.resize(b0 + b1 + b2 + b3);
+  char* k = victim->key.data();
+  std::memcpy(k, expX, b0);
+  std::memcpy(k + b0, inputs, b1);
+  std::memcpy(k + b0 + b1, invQt, b2);
+  if (invQ) std::memcpy(k + b0 + b1 + b2, invQ, b3);
+  victim->stamp = ++ctx->cache_clock;
+  *out = m;
+  return GP_OK;
+}
+
+// Host-pointer path = predict_wrap: the reference's twelve arguments.
 template <typename T, typename TH = T>
 static int predict_wrap(gp_ctx* ctx, const TH* expX, const TH* inputs, const TH* invQt,
                         const TH* invQ, const TH* testing, TH* result, TH* error, TH* deriv,
@@ -756,90 +1020,28 @@ static int predict_wrap(gp_ctx* ctx, const TH* expX, const TH* inputs, const TH*
   if (!ctx) return fail(GP_ERR_INVALID, "null context");
   if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
   if (M > 0 && (!testing || !result || !error || !deriv)) return fail(GP_ERR_INVALID, "null pointer");
+  if (!invQ) return fail(GP_ERR_INVALID, "null pointer");
   HIP_TRY(hipSetDevice(ctx->device));
   gp_model* m = nullptr;
-  int rc = model_create<T, TH>(ctx, 1, expX, inputs, invQt, invQ, N, D, theta_size, &m);
+  int rc = cached_model<T, TH>(ctx, expX, inputs, invQt, invQ, N, D, theta_size, &m);
   if (rc) return rc;
-  if (M == 0) { gp_model_destroy(m); return GP_OK; }
-  if (M >= kPipeMinRows || sizeof(T) != sizeof(TH)) {
-    rc = predict_host_pipelined<T, TH>(ctx, m, testing, result, error, deriv, M, D, layout);
-    gp_model_destroy(m);
-    return rc;
-  }
-  return predict_wrap_simple<T>(ctx, m, (const T*)(const void*)testing, (T*)(void*)result,
-                                (T*)(void*)error, (T*)(void*)deriv, M, D, layout);
+  return predict_host<T, TH>(ctx, m, testing, result, error, deriv, M, layout, 0);
 }
 
-// Small calls: pageable copies straight from/to the caller's arrays (T == TH here).
-template <typename T>
-static int predict_wrap_simple(gp_ctx* ctx, gp_model* m, const T* testing, T* result, T* error,
-                               T* deriv, int64_t M, int D, int layout) {
-  int rc = GP_OK;
-  const int64_t slab = M < (int64_t)(1 << 22) ? M : (int64_t)(1 << 22);  // rows per slab
-  const size_t per_row = sizeof(T) * (size_t)(2 * D + 2);
-  rc = ensure_scratch(ctx, per_row * (size_t)slab);
-  if (rc) { gp_model_destroy(m); return rc; }
-  hipError_t e = hipSuccess;
-  for (int64_t s0 = 0; s0 < M && rc == GP_OK && e == hipSuccess; s0 += slab) {
-    const int64_t n = (M - s0 < slab) ? (M - s0) : slab;
-    T* d_t = (T*)ctx->scratch;
-    T* d_mu = d_t + (size_t)n * D;
-    T* d_var = d_mu + n;
-    T* d_der = d_var + n;
-    e = hipMemcpyAsync(d_t, testing + (size_t)s0 * D, sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) break;
-    rc = predict_device<T>(ctx, m, d_t, d_mu, d_var, d_der, n, layout);
-    if (rc) break;
-    e = hipMemcpyAsync(result + s0, d_mu, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(error + s0, d_var, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
-    if (layout == GP_DERIV_ROWMAJOR) {
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(deriv + (size_t)s0 * D, d_der, sizeof(T) * (size_t)n * D,
-                           hipMemcpyDeviceToHost, ctx->stream);
-    } else {
-      // deriv is dimension-major over the WHOLE call: row d of the slab goes to d*M + s0
-      for (int d = 0; d < D && e == hipSuccess; ++d)
-        e = hipMemcpyAsync(deriv + (size_t)d * M + s0, d_der + (size_t)d * n, sizeof(T) * (size_t)n,
-                           hipMemcpyDeviceToHost, ctx->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  }
-  gp_model_destroy(m);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(GP_ERR_HIP, "predict_wrap: %s", hipGetErrorString(e));
-  return GP_OK;
-}
-
-// Host-pointer Hessian: constants + test rows up, one launch per slab, (M, D, D) down.
+// Host-pointer Hessian: constants (cached) + test rows up, (M, D, D) down.
 template <typename T>
 static int hessian_host(gp_ctx* ctx, const T* expX, const T* inputs, const T* invQt,
                         const T* testing, T* hess, int64_t M, int N, int D, int theta_size) {
   if (!ctx) return fail(GP_ERR_INVALID, "null context");
   if (M < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
   if (M > 0 && (!testing || !hess)) return fail(GP_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
   gp_model* m = nullptr;
-  int rc = model_create<T>(ctx, 1, expX, inputs, invQt, (const T*)nullptr, N, D, theta_size, &m);
+  int rc = cached_model<T, T>(ctx, expX, inputs, invQt, (const T*)nullptr, N, D, theta_size, &m);
   if (rc) return rc;
-  if (M == 0) { gp_model_destroy(m); return GP_OK; }
-  const int64_t slab = M < (int64_t)(1 << 20) ? M : (int64_t)(1 << 20);
-  const size_t per_row = sizeof(T) * (size_t)(D + D * D);
-  rc = ensure_scratch(ctx, per_row * (size_t)slab);
-  hipError_t e = hipSuccess;
-  for (int64_t s0 = 0; s0 < M && rc == GP_OK && e == hipSuccess; s0 += slab) {
-    const int64_t n = (M - s0 < slab) ? (M - s0) : slab;
-    T* d_t = (T*)ctx->scratch;
-    T* d_h = d_t + (size_t)n * D;
-    e = hipMemcpyAsync(d_t, testing + (size_t)s0 * D, sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) break;
-    rc = hessian_device<T>(ctx, m, d_t, d_h, n);
-    if (rc) break;
-    e = hipMemcpyAsync(hess + (size_t)s0 * D * D, d_h, sizeof(T) * (size_t)n * D * D, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  }
-  gp_model_destroy(m);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian: %s", hipGetErrorString(e));
-  return GP_OK;
+  if (m->n_inputs > GP_MAX_KERNEL_D)
+    return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
+  return hessian_host_model<T>(ctx, m, testing, hess, M);
 }
 
 extern "C" {
@@ -857,6 +1059,15 @@ int gp_batch_create_f32(gp_ctx* ctx, int n_emulators, const float* expX, const f
                         const float* invQt, const float* invQ, int n_train, int n_inputs,
                         int theta_size, gp_model** out) {
   return model_create<float>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+}
+int gp_model_create_f32_h64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
+                            const double* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
+  return model_create<float, double>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+}
+int gp_batch_create_f32_h64(gp_ctx* ctx, int n_emulators, const double* expX, const double* inputs,
+                            const double* invQt, const double* invQ, int n_train, int n_inputs,
+                            int theta_size, gp_model** out) {
+  return model_create<float, double>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
 }
 int gp_model_emulators(const gp_model* m, int* n_emulators) {
   if (!m || !n_emulators) return fail(GP_ERR_INVALID, "null pointer");
@@ -889,6 +1100,15 @@ int gp_model_info(const gp_model* m, int* dtype, int* n_train, int* n_inputs, in
   return GP_OK;
 }
 
+int gp_kernel_ksteps(int n_train, int n_inputs, int* ksteps) {
+  if (!ksteps) return fail(GP_ERR_INVALID, "null pointer");
+  int kd, knb, knk;
+  int rc = pick_kernel(n_train, n_inputs, &kd, &knb, &knk);
+  if (rc) return rc;
+  *ksteps = knk;
+  return GP_OK;
+}
+
 int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing, void* d_mu,
                       void* d_var, void* d_deriv, int64_t n_predict, int deriv_layout) {
   if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
@@ -903,6 +1123,48 @@ int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
   if (model->dtype == GP_F64)
     return predict_device<double>(ctx, model, d_testing, d_mu, d_var, d_deriv, n_predict, deriv_layout);
   return predict_device<float>(ctx, model, d_testing, d_mu, d_var, d_deriv, n_predict, deriv_layout);
+}
+
+int gp_predict_host(gp_ctx* ctx, const gp_model* model, int host_dtype, const void* testing,
+                    void* result, void* error, void* deriv, int64_t n_predict, int deriv_layout,
+                    int64_t max_block_rows) {
+  if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
+  if (n_predict < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
+  if (n_predict == 0) return GP_OK;
+  if (!testing || !result || !error || !deriv) return fail(GP_ERR_INVALID, "null pointer");
+  if (deriv_layout != GP_DERIV_DMAJOR && deriv_layout != GP_DERIV_ROWMAJOR)
+    return fail(GP_ERR_INVALID, "bad deriv_layout %d", deriv_layout);
+  if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  if (!model->d_frags) return fail(GP_ERR_INVALID, "model was created without invQ: no variance operand");
+  if (model->dtype == GP_F64 && host_dtype == GP_F64)
+    return predict_host<double, double>(ctx, model, (const double*)testing, (double*)result, (double*)error,
+                                        (double*)deriv, n_predict, deriv_layout, max_block_rows);
+  if (model->dtype == GP_F32 && host_dtype == GP_F32)
+    return predict_host<float, float>(ctx, model, (const float*)testing, (float*)result, (float*)error,
+                                      (float*)deriv, n_predict, deriv_layout, max_block_rows);
+  if (model->dtype == GP_F32 && host_dtype == GP_F64)
+    return predict_host<float, double>(ctx, model, (const double*)testing, (double*)result, (double*)error,
+                                       (double*)deriv, n_predict, deriv_layout, max_block_rows);
+  return fail(GP_ERR_INVALID, "host arrays must have the model's dtype, or be float64 for a float32 model");
+}
+
+int gp_hessian_host(gp_ctx* ctx, const gp_model* model, const void* testing, void* hess, int64_t n_predict) {
+  if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
+  if (n_predict < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
+  if (n_predict == 0) return GP_OK;
+  if (!testing || !hess) return fail(GP_ERR_INVALID, "null pointer");
+  if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  if (model->n_emulators != 1) return fail(GP_ERR_INVALID, "hessian is per emulator: batch of %d given", model->n_emulators);
+  if (model->n_inputs > GP_MAX_KERNEL_D)
+    return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
+  if (model->dtype == GP_F64) return hessian_host_model<double>(ctx, model, (const double*)testing, (double*)hess, n_predict);
+  return hessian_host_model<float>(ctx, model, (const float*)testing, (float*)hess, n_predict);
+}
+
+int gp_ctx_host_threads(gp_ctx* ctx, int* n_threads) {
+  if (!ctx || !n_threads) return fail(GP_ERR_INVALID, "null pointer");
+  *n_threads = host_threads();
+  return GP_OK;
 }
 
 int gp_predict_wrap_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,

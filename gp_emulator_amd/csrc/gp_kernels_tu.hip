@@ -1,6 +1,6 @@
-// One translation unit per (compute dtype, NB): instantiates predict_kernel<T, D, NB> for
+// One translation unit per (compute dtype, NK): instantiates predict_kernel<T, D, NK> for
 // every supported kernel D and exports one launcher.  Compiled several times by build.py
-// with -DGP_T=<float|double> -DGP_TNAME=<f32|f64> -DGP_NB=<blocks of 16 training points>.
+// with -DGP_T=<float|double> -DGP_TNAME=<f32|f64> -DGP_NK=<groups of 4 training points>.
 #include "gp_predict_kernel.hpp"
 #include "gp_dispatch.hpp"
 
@@ -11,11 +11,11 @@ namespace gpk {
 
 template <int D>
 static hipError_t launch_one(const PredictArgs<GP_T>& a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((predict_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(Geo<GP_T>::kThreads), 0, stream, a);
+  hipLaunchKernelGGL((predict_kernel<GP_T, D, GP_NK>), dim3(grid), dim3(Geo<GP_T>::kThreads), 0, stream, a);
   return hipGetLastError();
 }
 
-hipError_t GP_CAT(launch_predict_, GP_TNAME, GP_NB)(int kernel_d, const PredictArgs<GP_T>& a,
+hipError_t GP_CAT(launch_predict_, GP_TNAME, GP_NK)(int kernel_d, const PredictArgs<GP_T>& a,
                                                    int grid, hipStream_t stream) {
   switch (kernel_d) {
 #define GP_CASE(d) case d: return launch_one<d>(a, grid, stream);

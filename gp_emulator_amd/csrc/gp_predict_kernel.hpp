@@ -16,11 +16,17 @@
 //     staged once per workgroup in LDS and read as broadcasts;
 //   * phase B (MFMA): var = b - k^T invQ k as 16x16x4 MFMAs.  invQ arrives pre-packed in
 //     "fragment order" (one 64-lane A operand = 64 consecutive reals) and is streamed
-//     L2 -> LDS in double-buffered chunks shared by the 4 waves of the workgroup.  Only
-//     block pairs I <= J are visited: S'_IJ = invQ_IJ + invQ_JI^T (I < J), S'_JJ = invQ_JJ,
-//     an identity valid for ANY matrix (tests/benchmark.py:14 feeds a non-symmetric one).
-//   * 4 waves per workgroup (one per SIMD), 2 workgroups per CU: while one workgroup is in
-//     its MFMA phase the other runs its VALU phase on the same SIMDs.
+//     L2 -> LDS by LDS-DMA in double-buffered chunks shared by the waves of the workgroup.
+//     Only block pairs I >= J are visited: S'_IJ = invQ_IJ + invQ_JI^T (I > J), S'_JJ =
+//     invQ_JJ, an identity valid for ANY matrix (tests/benchmark.py:14 feeds a non-symmetric
+//     one).  The contraction runs over the training blocks I, and the kernel is compiled for
+//     a number of k-steps NK (groups of 4 training points), not of 16-blocks: the k-steps of
+//     the last block that would hold nothing but padding (N = 250 -> NK = 63: rows 252..255)
+//     are issued neither in phase A nor, for any column block J, in phase B;
+//   * geometry (struct Geo): fp64 8 waves per workgroup = two per SIMD, one workgroup per CU,
+//     all waves in the same phase (fp64 MFMA and fp64 VALU share one pipe, so there is
+//     nothing to overlap); fp32 12 waves = three per SIMD.  Persistent grid, one workgroup
+//     per CU, work items dealt round-robin.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -174,50 +180,38 @@ __host__ __device__ constexpr int own_index(int I, int s, int g) {
   return 16 * I + Real<T>::own_sub(s, g);
 }
 
-// Fragment order.  GP_PAIRED = 0: column block by column block, (J, I <= J, s).
-// GP_PAIRED = 1: column blocks in pairs (J0, J0 + 1) whose k-steps alternate, so that two
-// independent accumulator chains are in flight per wave (a single dependent fp64 MFMA chain
-// reaches 82 % of the matrix pipe from one wave per SIMD, two chains 93 % --
-// tools/mfma_f64_probe.hip).
-#ifndef GP_PAIRED
-#define GP_PAIRED 0
-#endif
+// Slot of training point n in the packed images (rows of xa, rows and columns of S'): inside its
+// 16-block the n'-th point goes to the row that k-step n' / 4 pairs with lane group n' % 4, so
+// the points of a partly filled last block fill whole k-steps first (fp64: the identity; fp32,
+// whose matrix-core rows are 4 g + r: a 4 x 4 transpose).  slot_point is the inverse.
+template <typename T>
+__host__ __device__ constexpr int point_slot(int n) {
+  return 16 * (n / 16) + Real<T>::own_sub((n % 16) / 4, n % 4);
+}
+template <typename T>
+__host__ __device__ constexpr int slot_point(int slot) {
+  for (int q = 0; q < 16; ++q)
+    if (Real<T>::own_sub(q / 4, q % 4) == slot % 16) return 16 * (slot / 16) + q;
+  return -1;
+}
+
+// Fragment order: column block by column block, (J, I >= J, s).  Fragment (I, J, s) is the
+// A operand of the MFMA that adds training block I's k-step s to column block J's accumulator:
+// lane l holds S'[16 I + own_sub(s, l >> 4)][16 J + (l & 15)].
 struct FragId { int I, J, s; };
 __host__ __device__ constexpr int frag_count(int NB) { return NB * (NB + 1) / 2 * 4; }
-// n-th fragment in consumption order (by simulation; evaluated at compile time in the kernel)
+// block pairs in front of column block J
+__host__ __device__ constexpr int frag_col_offset(int J, int NB) { return J * NB - J * (J - 1) / 2; }
+// n-th fragment in consumption order (evaluated at compile time in the kernel)
 __host__ __device__ constexpr FragId frag_at(int n, int NB) {
-#if GP_PAIRED
-  int cnt = 0;
-  for (int J0 = 0; J0 < NB; J0 += 2) {
-    const int J1 = J0 + 1 < NB ? J0 + 1 : -1;
-    const int Imax = J1 >= 0 ? J1 : J0;
-    for (int I = 0; I <= Imax; ++I)
-      for (int s = 0; s < 4; ++s) {
-        if (I <= J0) { if (cnt == n) return FragId{I, J0, s}; ++cnt; }
-        if (J1 >= 0) { if (cnt == n) return FragId{I, J1, s}; ++cnt; }
-      }
-  }
-  return FragId{0, 0, 0};
-#else
   const int pair = n >> 2;
   int J = 0;
-  while ((J + 1) * (J + 2) / 2 <= pair) ++J;
-  (void)NB;
-  return FragId{pair - J * (J + 1) / 2, J, n & 3};
-#endif
+  while (J + 1 < NB && frag_col_offset(J + 1, NB) <= pair) ++J;
+  return FragId{J + pair - frag_col_offset(J, NB), J, n & 3};
 }
-// position of fragment (I <= J, s) in consumption order (host-side packing and tests)
+// position of fragment (I >= J, s) in consumption order (host-side packing and tests)
 __host__ __device__ constexpr int frag_index(int I, int J, int s, int NB) {
-#if GP_PAIRED
-  for (int n = 0; n < frag_count(NB); ++n) {
-    const FragId f = frag_at(n, NB);
-    if (f.I == I && f.J == J && f.s == s) return n;
-  }
-  return -1;
-#else
-  (void)NB;
-  return (J * (J + 1) / 2 + I) * 4 + s;
-#endif
+  return (frag_col_offset(J, NB) + (I - J)) * 4 + s;
 }
 // The packed fragment buffer is padded to whole chunks so staging needs no bounds checks.
 __host__ __device__ constexpr int frag_count_padded(int NB, int chunk) {
@@ -231,7 +225,7 @@ __host__ __device__ constexpr int row_stride(int D) { return (D + 2 + 3) & ~3; }
 
 template <typename T>
 struct PredictArgs {
-  const T* xa;        // [16*NB][row_stride(D)]  training rows [x'', alpha, h] (zero padded)
+  const T* xa;        // [16*NB][row_stride(D)]  training rows [x'', alpha, h] (zero padded), NB = ceil(NK/4)
   const T* frags;     // [frag_count_padded(NB,kChunk)][64]  S' in fragment order
   const T* sd;        // [2*D + 1] sqrt(e_d), the centre c_d (training mean, input units), b = e[D]
   const T* testing;   // [M][d_actual] row-major test inputs (device)
@@ -248,6 +242,9 @@ struct PredictArgs {
   int n_emulators;
   long long xa_stride, frags_stride, sd_stride;
   unsigned long long* dbg;   // GP_STAMPS builds only: [8] segment cycle sums; else unused
+  // 1: `testing` already holds t'' = sqrt(e)(t - c) (scaled and centred in double by the host
+  // while staging float64 rows for a float32 predict); 0: raw rows, scaled here
+  int rows_prescaled;
 };
 
 // v[l] + v[l ^ 16] (XOR = 16) or v[l] + v[l ^ 32] (XOR = 32) in every lane, with gfx950's
@@ -308,8 +305,9 @@ __device__ inline T xor_reduce_groups(T v) {
 // asm form (cdna_hip_programming.md 5.7): nothing reads the destination buffer until the
 // issuing wave has run dma_wait() and the workgroup has passed a barrier.  Compiler-placed
 // vmcnt waits stay safe: un-counted extra operations can only make them wait longer.
-// M0 is a reserved register the compiler never allocates and reloads before each of its
-// own uses (none in this kernel), so the asm sets it without listing it as a clobber.
+// M0 (the DMA's LDS base) is compiler-reserved and not preserved around an asm statement, and
+// it cannot be listed as a clobber: the statement that reads it also writes it, and puts the
+// previous value back before it ends (cdna_hip_programming.md 5.7, "Operands and clobbers").
 template <typename T>
 __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int lane) {
   constexpr int kChunk = Geo<T>::kChunk;
@@ -328,11 +326,14 @@ __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int 
     if (pc0 + kWaves <= kPieces || pc < kPieces) {
       const char* s = reinterpret_cast<const char*>(src) + pc * 1024;
       const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + pc * 1024);
+      unsigned keep;
       asm volatile(
-          "s_mov_b32 m0, %0\n\t"
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %1\n\t"
           "s_nop 4\n\t"   /* covers VALU(v_readlane)->SGPR->VMEM and M0->LDS-DMA wait states */
-          "global_load_lds_dwordx4 %1, %2"
-          :
+          "global_load_lds_dwordx4 %2, %3\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
           : "s"(m0v), "v"(voff), "s"(s)
           : "memory");
     }
@@ -356,12 +357,15 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 #define GP_STAMP(seg) do { } while (0)
 #endif
 
-template <typename T, int D, int NB>
+// NK = k-steps (groups of 4 training points) the kernel is compiled for: n_train <= 4 NK.
+template <typename T, int D, int NK>
 __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predict_kernel(PredictArgs<T> p) {
   typedef Real<T> R;
   constexpr int kThreads = Geo<T>::kThreads;
   constexpr int kRowsPerWG = Geo<T>::kRowsPerWG;
   typedef typename R::acc_t acc_t;
+  constexpr int NB = (NK + 3) / 4;          // 16-blocks of training points
+  constexpr int KL = NK - 4 * (NB - 1);     // live k-steps of the last block, 1..4
   constexpr int NP = 16 * NB;
   constexpr int DS = row_stride(D);
   constexpr int NF = frag_count(NB);
@@ -371,6 +375,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
   __shared__ __attribute__((aligned(16))) T s_xa[NP * DS];
   __shared__ __attribute__((aligned(16))) T s_fr[2][kChunk * 64];
   __shared__ T s_sd[2 * D + 1];   // sqrt(e_d), centre c_d, b: broadcast reads, no registers
+  __shared__ T s_ts[2 * D];       // scale and centre applied to the test rows: s_sd's, or (1, 0)
   // raw test rows of the wave's tile, double-buffered and private to the wave: the NEXT item's
   // rows are fetched (coalesced, 8 or 4 B per lane) while the matrix-core phase runs and are
   // picked up from here at the top of that item -- all waves of a workgroup are in step, so
@@ -427,7 +432,12 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       const T* xa = p.xa + e * p.xa_stride;
       for (int i = tid; i < NP * DS; i += kThreads) s_xa[i] = xa[i];
       const T* sdp = p.sd + e * p.sd_stride;
-      if (tid < 2 * D + 1) s_sd[tid] = (tid == 2 * D || (tid % D) < p.d_actual) ? sdp[tid] : T(0);
+      if (tid < 2 * D + 1) {
+        const bool live = tid == 2 * D || (tid % D) < p.d_actual;
+        s_sd[tid] = live ? sdp[tid] : T(0);
+        if (tid < 2 * D)
+          s_ts[tid] = !live ? T(0) : !p.rows_prescaled ? sdp[tid] : tid < D ? T(1) : T(0);
+      }
     }
     const T* frags = p.frags + e * p.frags_stride;
     T* o_mu = p.mu + e * p.M;
@@ -457,8 +467,8 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int dc = d < p.d_actual ? d : p.d_actual - 1;
-        sdv[d] = s_sd[d];
-        cv[d] = s_sd[D + d];
+        sdv[d] = s_ts[d];
+        cv[d] = s_ts[D + d];
         rv[d] = s_rows[rbuf][wave][ml * p.d_actual + dc];
       }
 #pragma unroll
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
     fetch_rows(e_next < p.n_emulators ? grp_next : grp, rregs);
 
     GP_STAMP(1);   // test rows loaded and scaled
-    T kv[4 * NB];
+    T kv[NK];
     T mu = T(0);
     T ga[D];
 #pragma unroll
@@ -492,15 +502,15 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
     // group the loads are in flight together and the serial distance chains interleave.
     // fp64 has no registers to spare for that (kGroup = 1); fp32 does.
     constexpr int GP = R::kGroup;
-    static_assert((4 * NB) % GP == 0, "group size must divide the points per lane");
-    static_for<4 * NB / GP>([&](auto qc) {
+    static_for<(NK + GP - 1) / GP>([&](auto qc) {
       constexpr int q0 = decltype(qc)::value * GP;
+      constexpr int GU = NK - q0 < GP ? NK - q0 : GP;     // (the last group may be short)
       T x[GP][D];
       T al[GP];
       T k[GP];
       // stage 1: rows -> registers, exponent argument
 #pragma unroll
-      for (int u = 0; u < GP; ++u) {
+      for (int u = 0; u < GU; ++u) {
         const int q = q0 + u;
         const int i = own_index<T>(q >> 2, q & 3, g);
         const T* row = &s_xa[i * DS];
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
         if constexpr (R::kExpand) k[u] = row[D + 1] + gm;
       }
 #pragma unroll
-      for (int u = 0; u < GP; ++u) {
+      for (int u = 0; u < GU; ++u) {
 #if GP_ABLATE == 2
         continue;
 #endif
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       }
       // stage 2: kernel values
 #pragma unroll
-      for (int u = 0; u < GP; ++u) {
+      for (int u = 0; u < GU; ++u) {
 #if GP_ABLATE == 2
         k[u] = x[u][0] + t[0];
 #else
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       }
       // stage 3: mean and gradient sums
 #pragma unroll
-      for (int u = 0; u < GP; ++u) {
+      for (int u = 0; u < GU; ++u) {
         const T w = k[u] * al[u];
         mu += w;
 #if GP_ABLATE == 2
@@ -591,10 +601,9 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 
     // ---------------- phase B: variance on the matrix core -----------------
     T vacc = T(0);
-    acc_t acc, acc2;   // acc2: second chain (odd column block of a pair) when GP_PAIRED
-    (void)acc2;
+    acc_t acc;
 #if GP_ABLATE == 1
-    static_for<4 * NB>([&](auto qc) { vacc += kv[decltype(qc)::value]; });
+    static_for<NK>([&](auto qc) { vacc += kv[decltype(qc)::value]; });
     static_for<0>([&](auto fc) {
 #else
     static_for<NF>([&](auto fc) {
@@ -609,20 +618,13 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
         if constexpr (c + 1 < NCH)
           stage_chunk<T>(frags + (c + 1) * kChunk * 64, &s_fr[(c + 1) & 1][0], wave, lane);
       }
-      if constexpr (GP_PAIRED && (J & 1)) {
-        if constexpr (I == 0 && s == 0) acc2 = acc_t{T(0), T(0), T(0), T(0)};
-        acc2 = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc2);
-        if constexpr (I == J && s == 3) {
+      if constexpr (I == J && s == 0) acc = acc_t{T(0), T(0), T(0), T(0)};
+      // (k-steps s >= KL of the last training block are padding: not issued)
+      if constexpr (4 * I + s < NK) acc = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc);
+      if constexpr (I == NB - 1 && s == 3) {
+        // rows of the last column block beyond its KL registers are padding too (exactly 0)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vacc = fma(acc2[r], kv[4 * J + r], vacc);
-        }
-      } else {
-        if constexpr (I == 0 && s == 0) acc = acc_t{T(0), T(0), T(0), T(0)};
-        acc = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc);
-        if constexpr (I == J && s == 3) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) vacc = fma(acc[r], kv[4 * J + r], vacc);
-        }
+        for (int r = 0; r < (J == NB - 1 ? KL : 4); ++r) vacc = fma(acc[r], kv[4 * J + r], vacc);
       }
     });
     rbuf ^= 1;

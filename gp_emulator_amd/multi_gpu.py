@@ -35,36 +35,59 @@ def row_shards(n_rows, n_shards):
     return out
 
 
-def predict_sharded(gp, testing, devices, precision=np.float64, predict_fn=None):
+_device_ctx = {}
+_device_ctx_lock = threading.Lock()
+
+
+def _device_context(device):
+    """One long-lived (context, lock) per device for the sharded path: its helper threads,
+    pinned staging and streams are created once, not per call or per Python thread."""
+    from . import _lib
+    with _device_ctx_lock:
+        hit = _device_ctx.get(device)
+        if hit is None:
+            hit = _device_ctx[device] = (_lib.Context(device), threading.Lock())
+        return hit
+
+
+def predict_sharded(gp, testing, devices, precision=np.float64, predict_fn=None, out=None):
     """mean, variance, gradient of ``gp`` at ``testing`` with rows sharded over ``devices``.
 
-    ``predict_fn(device, rows) -> (mu, var, deriv)`` defaults to the HIP path (a Model per
-    device); the CPU tests pass a stand-in to exercise the sharding/gather logic alone.
+    Every device gets one contiguous row block and writes its results straight into its own
+    slice of the output arrays (``out=(mu, var, deriv)`` to reuse them) through the library's
+    slab pipeline (``Model.predict``): the gather is the D2H copy itself.
+    ``predict_fn(device, rows) -> (mu, var, deriv)`` replaces the HIP path in the CPU tests,
+    which exercise the sharding/gather logic alone.
     """
     testing = np.ascontiguousarray(testing)
     M, D = testing.shape
-    mu = np.empty(M)
-    var = np.empty(M)
-    deriv = np.empty((M, D))
+    if out is None:
+        mu, var, deriv = np.empty(M), np.empty(M), np.empty((M, D))
+    else:
+        mu, var, deriv = out
     shards = row_shards(M, len(devices))
     errors = []
 
-    if predict_fn is None:
+    def hip_shard(device, s, e):
         from . import _lib
-
-        def predict_fn(device, rows):
-            ctx = _lib.default_context(device)      # per-thread context on that device
+        ctx, lock = _device_context(device)
+        with lock:
             model = _lib.Model(ctx, np.exp(gp.theta), gp.inputs, gp.invQt, gp.invQ, precision)
             try:
-                return model.predict(rows)
+                rows = testing[s:e]
+                if rows.dtype != np.float64:
+                    rows = rows.astype(np.float64)
+                model.predict(rows, out=(mu[s:e], var[s:e], deriv[s:e]))
             finally:
                 model.close()
 
     def work(device, s, e):
         try:
             if e > s:
-                m_, v_, d_ = predict_fn(device, testing[s:e])
-                mu[s:e], var[s:e], deriv[s:e] = m_, v_, d_
+                if predict_fn is None:
+                    hip_shard(device, s, e)
+                else:
+                    mu[s:e], var[s:e], deriv[s:e] = predict_fn(device, testing[s:e])
         except BaseException as exc:   # surfaced to the caller below
             errors.append((device, exc))
 

@@ -97,6 +97,12 @@ class MultivariateEmulator(object):
             from . import _lib
             cost, grad, invQ, invQt = _lib.default_context(0).likelihood_batch(
                 self.hyperparams.T, np.atleast_2d(y), train_data, want_inverse=True)
+            bad = np.flatnonzero(~np.isfinite(cost))
+            if bad.size:
+                # a pivot of the elimination was <= 0: what the host branch (_set_params ->
+                # numpy's Cholesky, reference :66) reports as LinAlgError
+                raise np.linalg.LinAlgError("Matrix is not positive definite (principal component %d)"
+                                            % int(bad[0]))
             for i, gp in enumerate(self.emulators):
                 gp.theta = self.hyperparams[:, i].copy()
                 gp.invQ, gp.invQt = invQ[i], invQt[i]

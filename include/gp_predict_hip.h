@@ -122,6 +122,11 @@ int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs,
 int gp_model_create_f32(gp_ctx* ctx, const float* expX, const float* inputs,
                         const float* invQt, const float* invQ,
                         int n_train, int n_inputs, int theta_size, gp_model** out);
+/* float32 model packed from float64 constants (rounded once, after the double-precision
+ * scaling and folding): what a float32 predict on float64 data should use. */
+int gp_model_create_f32_h64(gp_ctx* ctx, const double* expX, const double* inputs,
+                            const double* invQt, const double* invQ,
+                            int n_train, int n_inputs, int theta_size, gp_model** out);
 /* Batched emulators: the per-band pattern of tests/test_perband_emulator.py:22-37 (one
  * GaussianProcess per band, all on the SAME training inputs, each with its own theta,
  * invQ, invQt), which the reference can only run as a Python loop over predict_wrap.
@@ -135,6 +140,9 @@ int gp_batch_create_f64(gp_ctx* ctx, int n_emulators, const double* expX, const 
 int gp_batch_create_f32(gp_ctx* ctx, int n_emulators, const float* expX, const float* inputs,
                         const float* invQt, const float* invQ,
                         int n_train, int n_inputs, int theta_size, gp_model** out);
+int gp_batch_create_f32_h64(gp_ctx* ctx, int n_emulators, const double* expX, const double* inputs,
+                            const double* invQt, const double* invQ,
+                            int n_train, int n_inputs, int theta_size, gp_model** out);
 int gp_model_emulators(const gp_model* model, int* n_emulators);
 int gp_model_destroy(gp_model* model);
 int gp_model_info(const gp_model* model, int* dtype, int* n_train, int* n_inputs,
@@ -147,6 +155,23 @@ int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
                       void* d_mu, void* d_var, void* d_deriv, int64_t n_predict,
                       int deriv_layout);
 
+/* The same launch for HOST arrays: testing [M*D] in, result / error [E][M] and deriv [E][M*D]
+ * (deriv_layout as above) out, where E = the model's number of emulators (1 unless batched).
+ * This is the body of gp_predict_wrap_* / gp_predict_rows_* without the per-call constants:
+ * rows flow in slabs through three slots (pinned staging, one stream each: H2D, kernel, D2H)
+ * while the calling thread and the context's helper threads (GP_HOST_THREADS, default 8) copy
+ * the next slab in and the previous one out of the caller's arrays.  host_dtype is the dtype of
+ * the four host arrays: the model's, or GP_F64 with a GP_F32 model -- rows are then centred and
+ * scaled in double and rounded once while they are staged, outputs widened on the way back.
+ * max_block_rows > 0 bounds the rows per launch (GaussianProcess.gpu_predict's `threshold`,
+ * gp_emulator/GaussianProcess.py:273,297-299); 0 = the library's own slab size.
+ * Returns when the outputs are written. */
+int gp_predict_host(gp_ctx* ctx, const gp_model* model, int host_dtype, const void* testing,
+                    void* result, void* error, void* deriv, int64_t n_predict, int deriv_layout,
+                    int64_t max_block_rows);
+/* number of host threads (caller included) the context uses for staging copies */
+int gp_ctx_host_threads(gp_ctx* ctx, int* n_threads);
+
 /* ---- Hessian of the mean ------------------------------------------------------------------
  * Replaces GaussianProcess.hessian (gp_emulator/GaussianProcess.py:345-366; the reference
  * has NO native version of it).  hess is (n_predict, n_inputs, n_inputs) row-major.
@@ -157,6 +182,9 @@ int gp_predict_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
  * call on a model packs and uploads that kernel's constant operand (once, thread-safe). */
 int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
                       void* d_hess, int64_t n_predict);
+/* host arrays of the model's dtype in and out, through the same slab pipeline as gp_predict_host */
+int gp_hessian_host(gp_ctx* ctx, const gp_model* model, const void* testing, void* hess,
+                    int64_t n_predict);
 int gp_hessian_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                    const double* testing, double* hess,
                    int64_t n_predict, int n_train, int n_inputs, int theta_size);
@@ -188,8 +216,12 @@ int gp_likelihood_batch_f64(gp_ctx* ctx, int n_sets, const double* theta, const 
 /* Host-side packing only (no GPU needed): what gp_model_create_* uploads.  xa and frags
  * are sized by gp_pack_sizes; sd takes 2*kernel_d + 1 reals (sqrt(e_d), the centre c_d, b);
  * used by the CPU tests to check the fragment layout. */
-/* position (in units of 64-real fragments) of fragment (I <= J, k-step s) in the packed buffer */
+/* position (in units of 64-real fragments) of fragment (I >= J, k-step s) in the packed buffer */
 int gp_frag_index(int kernel_nb, int I, int J, int s);
+/* k-steps (groups of 4 training points) of the predict kernel chosen for this shape; k-steps
+ * 4 I + s beyond it exist in the packed buffer (as zeros) but are never issued.  0 = the
+ * general-shape kernel. */
+int gp_kernel_ksteps(int n_train, int n_inputs, int* ksteps);
 int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kernel_nb,
                   int64_t* xa_len, int64_t* frags_len);
 int gp_pack_model_f64(const double* expX, const double* inputs, const double* invQt,

@@ -55,14 +55,19 @@ def mfma_rows(dtype):
 @pytest.mark.parametrize("name", ["odd_n37_d3", "c1_n100_d5", "c2_n250_d11", "c4_n300_d11"])
 def test_packed_fragments_reproduce_quadratic_form(name, dtype):
     """Emulate, in numpy, exactly what the kernel does with the packed buffers:
-    16x16x4 matrix-core steps over block pairs I <= J, operands taken lane by lane from
-    the fragment buffer, result rows read back per lane -- and check
+    16x16x4 matrix-core steps over block pairs I >= J, operands taken lane by lane from
+    the fragment buffer, only the k-steps the chosen kernel issues (N = 250 -> 63 of 64,
+    N = 300 -> 75 of 76), result rows read back per lane -- and check
     k^T invQ k (invQ NON-symmetric) and mean/gradient against the oracle."""
     g = synthetic_case(name)
     N, D = g["inputs"].shape
     pk = _lib.pack_model(np.exp(g["theta"]), g["inputs"], g["invQt"], g["invQ"], dtype)
-    kd, nb = pk["kernel_d"], pk["kernel_nb"]
-    assert kd >= D and 16 * nb >= N
+    kd, nb, nk = pk["kernel_d"], pk["kernel_nb"], pk["kernel_nk"]
+    assert kd >= D and 4 * nk >= N and nb == (nk + 3) // 4
+    if name == "c2_n250_d11":
+        assert nk == 63
+    if name == "c4_n300_d11":
+        assert nk == 75
     ds = (kd + 2 + 3) & ~3
     xa = pk["xa"].astype(np.float64).reshape(16 * nb, ds)
     frags = pk["frags"].astype(np.float64).reshape(-1, 64)
@@ -71,24 +76,34 @@ def test_packed_fragments_reproduce_quadratic_form(name, dtype):
     own = mfma_rows(dtype)
     lanes = np.arange(64)
     grp, col = lanes >> 4, lanes & 15
+    # every training point sits in exactly one slot; slots of k-steps >= nk are zero padding
+    live = np.zeros(16 * nb, bool)
+    for q in range(nk):
+        for gq in range(4):
+            live[16 * (q // 4) + own(q % 4, gq)] = True
+    assert int(np.count_nonzero(np.any(xa != 0, axis=1))) == N
+    assert not np.any(xa[~live])
 
     T = g["testing"][:16]
     tp = np.zeros((16, kd))
     tp[:, :D] = sd[:D] * (T.astype(dtype).astype(np.float64) - ctr[:D])
-    # K tile, mean, gradient the way phase A forms them:
+    # K tile, mean, gradient the way phase A forms them (live k-steps only):
     #   k_i = exp(h_i + g + x''_i . t''),  G_d = sum_i w_i x''_id,  grad = sd (G - t'' mu)
     gm = -0.5 * np.sum(tp * tp, axis=1)
     K = np.exp(xa[:, kd + 1][:, None] + gm[None, :] + xa[:, :kd] @ tp.T)   # (NP, 16)
-    w = K * xa[:, kd][:, None]
+    K[~live] = np.nan                                      # never computed by the kernel
+    w = K[live] * xa[live, kd][:, None]
     mu = w.sum(axis=0)
-    G = w.T @ xa[:, :kd]
+    G = w.T @ xa[live, :kd]
     grad = ((G - tp * mu[:, None]) * sd[None, :])[:, :D]
     # phase B
     quad = np.zeros(16)
     for J in range(nb):
         acc = np.zeros((16, 16))                              # [row j_local][col m]
-        for I in range(J + 1):
+        for I in range(J, nb):
             for s in range(4):
+                if 4 * I + s >= nk:
+                    continue
                 f = frags[_lib.load().gp_frag_index(nb, I, J, s)]
                 A = np.zeros((16, 4))
                 A[col, grp] = f                               # A[row = l&15][k = l>>4]
@@ -97,7 +112,8 @@ def test_packed_fragments_reproduce_quadratic_form(name, dtype):
                 acc += A @ B
         for gq in range(4):
             for r in range(4):
-                quad += acc[own(r, gq), :] * K[16 * J + own(r, gq), :]
+                if 4 * J + r < nk:
+                    quad += acc[own(r, gq), :] * K[16 * J + own(r, gq), :]
     var = pk["b"] - quad
     o_mu, o_var, o_der = gp_oracle.cpu_predict(g["inputs"], g["theta"], g["invQ"], g["invQt"], T)
     tol = 1e-12 if np.dtype(dtype) == np.float64 else 5e-6
