@@ -11,12 +11,24 @@ that is ALREADY RESIDENT in HBM; outputs stay in HBM.  With N ranks every rank o
 (SURVEY.md section 8e), so scaling is weak.  torch is imported only for the multi-rank
 barrier / max-reduce (gloo); the product path is ctypes -> libgp_predict_hip.so.
 
-Extra objects on the JSON line:
-  roofline      the fused kernel against the FP64 matrix-core peak (the binding roofline,
-                arithmetic intensity ~746 flop/B); ``hbm`` gives the same launch against
-                the HBM roofline, which is what BASELINE.json's north star asks to see.
-  cpu_baseline  the numpy path (oracle = py3 restatement of the reference's cpu_predict)
-                timed on this box's host cores on a bounded sample; rank 0, N=1 only.
+Extra objects on the JSON line (flat scalars only inside each: the driver's record keeps those):
+  roofline      the fused kernel against the FP64 pipe peak (matrix = vector on MI355X; the
+                binding roofline, arithmetic intensity ~746 flop/B).  ``achieved`` / ``frac`` count
+                the flops the kernel EXECUTES (matrix instructions issued + phase-A arithmetic),
+                so frac <= 1; ``algorithmic_ratio`` is the un-halved count of SURVEY.md 8d over
+                the same peak (it exceeds 1: symmetric folding halves the variance work);
+                ``hbm_gbps`` / ``hbm_frac`` put the same launch against the 8 TB/s HBM roofline
+                (the figure BASELINE.json's north star asks for); ``e2e_points_per_s`` is
+                gp.predict(is_gpu=True) from host numpy arrays to host numpy arrays, what the
+                reference's tests/benchmark.py:41-44 times (never ``value``).
+  cpu_baseline  the numpy path (oracle = py3 restatement of the reference's cpu_predict) on this
+                box's host cores, rank 0, N=1 only: ``value`` as the reference runs it (one
+                process, BLAS threads = the cpu share), ``all_cores_value`` one single-threaded
+                worker process per cpu of the share over disjoint row shards.
+
+``--workload c4 --scaling strong`` is the BASELINE configs[3] run proper: a FIXED total of
+--total-rows (default 1e8) test rows split over the ranks, every rank predicting its shard from
+host arrays into its slice of ONE shared host array (/dev/shm), i.e. the host gather is timed.
 """
 import argparse
 import json
@@ -75,32 +87,79 @@ def parse():
     ap.add_argument("--no-parity", action="store_true",
                     help="timing-only ablation builds (tools/ab_bench.py): do not stop on a parity failure")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="worker processes of the all-cores CPU leg (0 = the cpu share, at most 16)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong (c4 only): fixed --total-rows split over the ranks, host arrays in, "
+                         "shared host array out")
+    ap.add_argument("--total-rows", type=int, default=100000000)
+    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(sample_rows):
-    """numpy path on the host: the oracle's restatement of GaussianProcess.cpu_predict
-    (scipy cdist + numpy; BLAS threads = all cores for the np.dot calls, everything else
-    single-threaded -- exactly how the reference runs it)."""
-    from oracle import gp_oracle
-    inputs, testing, theta, invQ, invQt = synthetic_inputs(12345, N_TRAIN, N_INPUTS, sample_rows)
+def cpu_share():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))              # the GPU box gives one GPU a 16-cpu share
+
+
+def cpu_worker(spec):
+    """One worker of the all-cores leg (its own process, BLAS pinned to one thread by the
+    parent's environment): ``seed,rows`` -> predicts its own seeded shard, prints the seconds."""
+    from oracle import gp_oracle
+    seed, rows = (int(x) for x in spec.split(","))
+    inputs, _, theta, invQ, invQt = synthetic_inputs(12345, N_TRAIN, N_INPUTS, 1)
+    testing = np.random.RandomState(seed).random_sample((rows, N_INPUTS))
+    gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[:1000])      # warm up
+    t0 = time.perf_counter()
+    gp_oracle.cpu_predict_blocked(inputs, theta, invQ, invQt, testing, block=20000)
+    print("%.6f" % (time.perf_counter() - t0), flush=True)
+
+
+def cpu_baseline(sample_rows, procs):
+    """numpy path on the host (both variants).  Runs BEFORE anything touches
+    the GPU, so starting worker processes is an ordinary fork + exec.
+    (1) as the reference runs it: the oracle's restatement of GaussianProcess.cpu_predict in ONE
+        process (scipy cdist + numpy; BLAS threads = the cpu share for the np.dot calls,
+        everything else single-threaded);
+    (2) all cores: one worker process per cpu of the share, BLAS single-threaded, disjoint
+        seeded row shards; rows of all workers / wall time from first start to last exit."""
+    import subprocess
+    from oracle import gp_oracle
     from threadpoolctl import threadpool_limits
-    blas_threads = max(1, min(avail, 16))       # the GPU box gives one GPU a 16-cpu share
+    inputs, testing, theta, invQ, invQt = synthetic_inputs(12345, N_TRAIN, N_INPUTS, sample_rows)
+    blas_threads = cpu_share()
     with threadpool_limits(limits=blas_threads):
         gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[:2000])   # warm up
         t0 = time.perf_counter()
         gp_oracle.cpu_predict_blocked(inputs, theta, invQ, invQt, testing, block=50000)
         dt = time.perf_counter() - t0
+    del testing
+    procs = procs or blas_threads
+    rows_each = max(1000, sample_rows // procs)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    t0 = time.perf_counter()
+    ws = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                            "%d,%d" % (777 + w, rows_each)], env=env, stdout=subprocess.PIPE, text=True)
+          for w in range(procs)]
+    inner = [float(w.communicate()[0].strip().splitlines()[-1]) for w in ws]
+    wall = time.perf_counter() - t0
+    if any(w.returncode != 0 for w in ws):
+        raise SystemExit("cpu_baseline worker failed")
     return {"value": sample_rows / dt, "unit": "test-points/s",
             "cores": int(blas_threads), "kind": "port",
             "sample": "%d rows of the same N=250, D=11 workload in 50k-row blocks, %.1f s; "
                       "numpy+scipy path (oracle/gp_oracle.py), BLAS threads=%s of %d host "
                       "cpus, elementwise/cdist/exp single-threaded as in the reference"
-                      % (sample_rows, dt, blas_threads, os.cpu_count() or 0)}
+                      % (sample_rows, dt, blas_threads, os.cpu_count() or 0),
+            "all_cores_value": procs * rows_each / max(inner),
+            "all_cores_procs": int(procs),
+            "all_cores_sample": "%d single-threaded worker processes x %d rows in 20k-row blocks, slowest "
+                                "worker %.1f s (%.1f s wall with interpreter start-up)"
+                                % (procs, rows_each, max(inner), wall)}
 
 
 WORKLOADS = {
@@ -231,8 +290,152 @@ def bench_train(a):
     return out
 
 
+def executed_flop_per_point(N, D, kind, minfo, hess_mfma):
+    """Flops the kernel EXECUTES per test point on the fp64 (or fp32) pipe.
+    predict: matrix instructions issued -- k-steps (4 I + s) < NK of block pairs I >= J, 2048 flop
+    each per 16 rows -- plus phase A's arithmetic (everything of SURVEY.md 8d but the variance).
+    Hessian (matrix core): 4 x 4 blocks bi <= bj of the D x D matrix, 4 NB instructions per block and
+    16-row tile, plus phase A (kernel row, weights, s, G_d); Hessian (VALU): the upper triangle."""
+    nb, kd = minfo["kernel_nb"], minfo["kernel_d"]
+    if kind == "hessian":
+        phase_a = 3 * N * D + 3 * N + 2 * N + 2 * N * D
+        if hess_mfma:
+            nb4 = (kd + 3) // 4
+            return nb4 * (nb4 + 1) // 2 * 4 * nb * 2048 // 16 + phase_a
+        return 2 * 16 * ((N + 15) // 16) * kd * (kd + 1) // 2 + phase_a
+    nk = minfo["kernel_nk"]
+    issued = sum(1 for J in range(nb) for I in range(J, nb) for s_ in range(4) if 4 * I + s_ < nk)
+    phase_a = 3 * N * D + 3 * N + 2 * N + (3 * N * D + D)
+    return issued * 2048 // 16 + phase_a
+
+
+def sample_parity(ctx, a, kind, bufs_out, inputs, testing, params, M, D, E, dtype):
+    """Spot check of what was timed against the oracle: sampled rows of the first, a middle and
+    the last emulator, mean, variance AND gradient (rows are copied back one by one, so config 3's
+    18 GB of gradients never cross PCIe whole)."""
+    from oracle import gp_oracle
+    from threadpoolctl import threadpool_limits
+    rs = np.random.RandomState(5)
+    isz = np.dtype(dtype).itemsize
+    # (one BLAS thread: a pool of spinning BLAS workers would eat into the cpu share the
+    # host-to-host leg's helper threads run on)
+    limit = threadpool_limits(limits=1)
+    if kind == "hessian":
+        idx = np.sort(rs.choice(M, 256, replace=False))
+        got = np.stack([ctx.to_host_at(bufs_out[0], i * D * D * isz, (D, D), dtype) for i in idx])
+        theta, invQ, invQt = params(0)
+        ref = gp_oracle.hessian(inputs, theta, invQt, testing[idx])
+        return {"e_hess": maxnorm_err(ref, got)}, len(idx)
+    d_mu, d_var, d_der = bufs_out
+    n_rows = 2048 if E == 1 else 256
+    idx = np.sort(rs.choice(M, n_rows, replace=False))
+    worst = {"e_mu": 0.0, "e_var": 0.0, "e_deriv": 0.0}
+    for e in sorted(set([0, E // 2, E - 1])):
+        theta, invQ, invQt = params(e)
+        mu = np.array([ctx.to_host_at(d_mu, (e * M + i) * isz, (), dtype) for i in idx])
+        var = np.array([ctx.to_host_at(d_var, (e * M + i) * isz, (), dtype) for i in idx])
+        der = np.stack([ctx.to_host_at(d_der, (e * M + i) * D * isz, (D,), dtype) for i in idx])
+        ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[idx])
+        for k, r, g in zip(("e_mu", "e_var", "e_deriv"), ref, (mu, var, der)):
+            worst[k] = max(worst[k], maxnorm_err(r, g))
+    return worst, n_rows * len(set([0, E // 2, E - 1]))
+
+
+def e2e_leg(N, D, M, inputs, testing, theta, invQ, invQt, dtype):
+    """gp.predict(is_gpu=True) from host numpy arrays to host numpy arrays (default threshold),
+    the call tests/benchmark.py:41-44 times; median of 10 calls after 3 warm-up calls."""
+    from gp_emulator_amd import GaussianProcess
+    gp = GaussianProcess(inputs, [])
+    gp.theta, gp.invQ, gp.invQt = theta, invQ, invQt
+    ts = []
+    for k in range(13):
+        t0 = time.perf_counter()
+        out = gp.predict(testing, is_gpu=True, precision=dtype)
+        ts.append(time.perf_counter() - t0)
+        del out
+    first, steady = ts[0], float(np.median(ts[3:]))
+    return M / steady, steady, first
+
+
+def bench_strong(a, grp):
+    """--workload c4 --scaling strong: BASELINE configs[3] as the north star states it -- a fixed
+    total of test rows row-sharded over the ranks, constants replicated, every rank predicting its
+    shard host-to-host through the slab pipeline into ITS slice of one shared host array
+    (/dev/shm): the gather is the D2H staging copy itself, there is no collective."""
+    from gp_emulator_amd import _lib, multi_gpu
+    rank, world = grp.rank, grp.world
+    N, D = 300, 11
+    total = int(a.total_rows)
+    lo, hi = multi_gpu.row_shards(total, world)[rank]
+    M = hi - lo
+    dtype = np.float64 if a.precision == "f64" else np.float32
+    inputs, _, theta, invQ, invQt = synthetic_inputs(1000, N, D, 1)
+    testing = np.empty((M, D))
+    for s0 in range(0, M, 1 << 20):                    # per-shard seeded generation, bounded temporaries
+        n = min(1 << 20, M - s0)
+        testing[s0:s0 + n] = np.random.RandomState(2000 + (lo + s0) // (1 << 20)).random_sample((n, D))
+    path = os.environ.get("GP_BENCH_SHM", "/dev/shm/gp_bench_c4_%s.bin" % os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        shared = multi_gpu.SharedOutputs(path, total, D, create=True)
+    grp.barrier()
+    if rank != 0:
+        shared = multi_gpu.SharedOutputs(path, total, D, create=False)
+    out = shared.views(lo, hi)
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
+    ctx = _lib.Context(grp.local_rank % ndev)
+    info = ctx.device_info()
+    model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, dtype)
+
+    def step():
+        model.predict(testing, out=out)
+    dt = multi_gpu.timed_steps(grp, step, ctx.synchronize, a.steps, a.warmup)
+    # parity of this rank's slice of the gathered array (oracle = checker, after the timed region)
+    from oracle import gp_oracle
+    idx = np.sort(np.random.RandomState(5 + rank).choice(M, 1024, replace=False))
+    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[idx])
+    errs = [maxnorm_err(r, g[idx]) for r, g in zip(ref, out)]
+    tol = 1e-10 if a.precision == "f64" else 1e-4
+    worst = grp.max(max(errs))
+    if not worst <= tol and not a.no_parity:
+        raise SystemExit("bench parity check failed on rank %d: %s" % (rank, errs))
+    outd = None
+    if rank == 0:
+        value = a.steps * total / dt
+        outd = {
+            "metric": "test-points/sec for predict(mean+var+grad), N_train=300 D=11",
+            "value": value, "unit": "test-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: N_train=300, D=11, N_test=%d in all, row-sharded over %d "
+                                   "rank(s) (%d rows each), host numpy arrays in, one shared host array out "
+                                   "(host gather, no collective), predict mean+var+grad" % (total, world, M),
+                       "n_train": N, "n_inputs": D, "n_test_total": total, "n_test_per_gpu": M,
+                       "parallelism": "row-sharded x%d, host gather, no collective" % world,
+                       "device": info["name"], "host_threads_per_rank": ctx.host_threads()},
+            "roofline": {"bound": "hbm", "achieved": value * 192 / 1e9, "peak": PEAK_HBM_GBPS * world, "unit": "GB/s",
+                         "frac": value * 192 / 1e9 / (PEAK_HBM_GBPS * world), "traffic": None,
+                         "kernel": "predict_kernel<%s,11,75> behind the host slab pipeline" % ("double" if a.precision == "f64" else "float"),
+                         "pcie_gbps_per_gpu": value * 192 / 1e9 / world,
+                         "note": "host-to-host: bound by PCIe (192 B per point over a link that moved 55-62 GB/s "
+                                 "for both directions together on the 1-GPU box, profiles/r02_host_path_experiments.txt) "
+                                 "and by host DRAM when several GPUs stream at once, not by HBM or the fp64 pipe"},
+            "parity": {"worst_over_ranks": worst, "tol": tol, "checked_rows_per_rank": 1024},
+        }
+        print(json.dumps(outd), flush=True)
+    grp.barrier()
+    del out
+    model.close()
+    shared.close(unlink=rank == 0)
+    grp.close()
+    return outd
+
+
 def main():
     a = parse()
+    if a.cpu_worker:
+        return cpu_worker(a.cpu_worker)
     if a.workload == "mv":
         return bench_reconstruct(a)
     if a.workload == "train":
@@ -243,6 +446,15 @@ def main():
     rank, world = grp.rank, grp.world
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.scaling == "strong":
+        if a.workload != "c4":
+            raise SystemExit("--scaling strong is the c4 workload's mode")
+        return bench_strong(a, grp)
+    # the CPU legs run first: they start worker processes, which must not happen once this
+    # process has initialised the GPU
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
+        cpu = cpu_baseline(a.cpu_sample, a.cpu_procs)
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
@@ -258,29 +470,30 @@ def main():
     d_t = ctx.to_device(testing.astype(dtype))
     if kind == "batch":
         # shared inputs / test rows; per-emulator theta, invQ, invQt from seed + e
+        def params(e):
+            r = np.random.RandomState(5000 + e)
+            return r.random_sample(D + 2), r.random_sample((N, N)), r.random_sample(N)
         thetas = np.empty((E, D + 2))
-        invQs = np.empty((E, N, N), dtype=dtype)
+        invQs = np.empty((E, N, N))
         invQts = np.empty((E, N))
         for e in range(E):
-            r = np.random.RandomState(5000 + e)
-            thetas[e] = r.random_sample(D + 2)
-            invQs[e] = r.random_sample((N, N))
-            invQts[e] = r.random_sample(N)
+            thetas[e], invQs[e], invQts[e] = params(e)
         model = _lib.BatchModel(ctx, np.exp(thetas), inputs, invQts, invQs, dtype)
-        if E > 64:
-            del invQs
+        del invQs
     else:
+        def params(e):
+            return theta, invQ, invQt
         model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, dtype)
     if kind == "hessian":
         d_h = ctx.malloc(M * D * D * isz)
-        bufs = [d_t, d_h]
+        bufs, outs = [d_t, d_h], [d_h]
 
         def step():
             model.hessian_device(d_t, d_h, M)
     else:
         d_mu, d_var = ctx.malloc(E * M * isz), ctx.malloc(E * M * isz)
         d_der = ctx.malloc(E * M * D * isz)
-        bufs = [d_t, d_mu, d_var, d_der]
+        bufs, outs = [d_t, d_mu, d_var, d_der], [d_mu, d_var, d_der]
 
         def step():
             model.predict_device(d_t, d_mu, d_var, d_der, M, _lib.GP_DERIV_ROWMAJOR)
@@ -306,83 +519,46 @@ def main():
     kern_ms = [ctx.elapsed_ms(evs[k], evs[k + 1]) for k in range(a.steps)]
     kern_avg_s = float(np.mean(kern_ms)) * 1e-3
 
-    # parity spot check of what was timed (after the timed region: the numpy check leaves
-    # BLAS worker threads spinning, which would steal host time from the launch loop)
-    # (the oracle enters only here, as the checker, and in the cpu_baseline leg)
-    from oracle import gp_oracle
-    rs = np.random.RandomState(5)
+    # parity spot check of what was timed (after the timed region; the oracle enters only here,
+    # as the checker, and in the cpu_baseline leg)
     tol = 1e-10 if a.precision == "f64" else 1e-4
-    if kind == "hessian":
-        idx = np.sort(rs.choice(M, 256, replace=False))
-        got = ctx.to_host(d_h, (M, D, D), dtype)[idx]
-        ref = gp_oracle.hessian(inputs, theta, invQt, testing[idx])
-        errs = [maxnorm_err(ref, got)]
-        names = ["e_hess"]
-    else:
-        idx = rs.choice(M, 2048, replace=False)
-        e_chk = E - 1
-        mu = ctx.to_host(d_mu, (E, M), dtype)[e_chk, idx]
-        var = ctx.to_host(d_var, (E, M), dtype)[e_chk, idx]
-        if E * M * D * isz < (4 << 30):
-            der = ctx.to_host(d_der, (E, M, D), dtype)[e_chk, idx]
-        else:                             # config 3 at full size: 18 GB of gradients
-            der = None
-        if kind == "batch":
-            r = np.random.RandomState(5000 + e_chk)
-            th_c, iq_c, iqt_c = r.random_sample(D + 2), r.random_sample((N, N)), r.random_sample(N)
-        else:
-            th_c, iq_c, iqt_c = theta, invQ, invQt
-        ref = gp_oracle.cpu_predict(inputs, th_c, iq_c, iqt_c, testing[idx])
-        errs = [maxnorm_err(ref[0], mu), maxnorm_err(ref[1], var)]
-        names = ["e_mu", "e_var"]
-        if der is not None:
-            errs.append(maxnorm_err(ref[2], der))
-            names.append("e_deriv")
-    if not max(errs) <= tol and not a.no_parity:
-        raise SystemExit("bench parity check failed: %s" % dict(zip(names, errs)))
+    errs, n_checked = sample_parity(ctx, a, kind, outs, inputs, testing, params, M, D, E, dtype)
+    if not max(errs.values()) <= tol and not a.no_parity:
+        raise SystemExit("bench parity check failed: %s" % errs)
 
     out = None
     if rank == 0:
         units = E * M                                  # (emulator, test point) pairs per step
         value = world * a.steps * units / dt
+        minfo = model.info()
+        hess_mfma = (kind == "hessian" and minfo["kernel_d"] in (8, 10, 11, 12, 16)
+                     and minfo["kernel_nb"] > 0 and not int(os.environ.get("GP_HESS_VALU", "0")))
         flop_pt = flop_per_point(N, D, kind)
+        exec_flop_pt = executed_flop_per_point(N, D, kind, minfo, hess_mfma)
         if kind == "hessian":
             byte_pt = (D + D * D) * isz
         else:
             byte_pt = (2 * D + 2) * isz if E == 1 else (2 + D) * isz
         peak = PEAK_FP64_TFLOPS if a.precision == "f64" else 157.3
-        achieved_tf = flop_pt * units / kern_avg_s / 1e12
+        executed_tf = exec_flop_pt * units / kern_avg_s / 1e12
         hbm_gbps = byte_pt * units / kern_avg_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (a.workload, a.precision))
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/traffic_%s_%s.json (static: rocprofv3 --pmc passes of %s, "
+                                  "not measured in this run)" % (a.workload, a.precision, tj.get("round", "an earlier round")))
             except Exception:
                 traffic = None
-        # what the kernel really executes on the dominant pipe (not the algorithmic count above):
-        # folded variance = 4 NB(NB+1)/2 MFMAs of 16x16x4 per 16-row tile; Hessian = D(D+1)/2 fmas
-        # per (training point, test point) over the padded training set
-        nb_pad = model.info()["kernel_nb"] if kind != "hessian" else (N + 15) // 16
-        hess_mfma = (kind == "hessian" and model.info()["kernel_d"] in (8, 10, 11, 12, 16)
-                     and model.info()["kernel_nb"] > 0 and not int(os.environ.get("GP_HESS_VALU", "0")))
-        if hess_mfma:
-            # 4 x 4 blocks (bi <= bj) of the D x D matrix, 4 NB MFMAs of 16x16x4 each per 16-row tile
-            nb4 = (model.info()["kernel_d"] + 3) // 4
-            exec_flop_pt = nb4 * (nb4 + 1) // 2 * 4 * model.info()["kernel_nb"] * 2048 // 16
-        elif kind == "hessian":
-            kd = model.info()["kernel_d"]
-            exec_flop_pt = 2 * 16 * nb_pad * kd * (kd + 1) // 2
-        else:
-            exec_flop_pt = 4 * nb_pad * (nb_pad + 1) // 2 * 2048 // 16
-        executed_tf = exec_flop_pt * units / kern_avg_s / 1e12
-        kname = {"predict": "predict_kernel", "batch": "predict_kernel", "hessian": "hessian_kernel"}[kind]
         ctype = "double" if a.precision == "f64" else "float"
-        minfo = model.info()
         if hess_mfma:
-            kname = "hessian_mfma_kernel"
-        kfull = ("%s<%s,%d,%d>" % (kname, ctype, minfo["kernel_d"], minfo["kernel_nb"])
-                 if kind != "hessian" or hess_mfma else "%s<%s,%d>" % (kname, ctype, minfo["kernel_d"]))
+            kfull = "hessian_mfma_kernel<%s,%d,%d>" % (ctype, minfo["kernel_d"], minfo["kernel_nb"])
+        elif kind == "hessian":
+            kfull = "hessian_kernel<%s,%d>" % (ctype, minfo["kernel_d"])
+        else:
+            kfull = "predict_kernel<%s,%d,%d>" % (ctype, minfo["kernel_d"], minfo["kernel_nk"])
         metric = ("test-points/sec for predict(mean+var+grad), N_train=%d D=%d" % (N, D)
                   if kind != "hessian" else
                   "test-points/sec for hessian (full DxD), N_train=%d D=%d" % (N, D))
@@ -392,6 +568,22 @@ def main():
             "c4": "BASELINE configs[3]: N_train=300, D=11, N_test=%d per GPU per step (1e8 rows row-sharded over 8 GPUs = 1.25e7 each), predict mean+var+grad" % M,
             "c5": "Hessian path (BASELINE configs[4]): N_train=300, D=16, N_test=%d per GPU per step, full DxD Hessian per test point" % M,
         }[a.workload]
+        roof = {"bound": "mfma", "achieved": executed_tf, "peak": peak,
+                "unit": "TFLOP/s", "frac": executed_tf / peak, "traffic": traffic,
+                "traffic_source": traffic_source,
+                "kernel": kfull, "kernel_ms": kern_avg_s * 1e3,
+                "executed_flop_per_point": exec_flop_pt,
+                "flop_per_point": flop_pt,
+                "algorithmic_tflops": flop_pt * units / kern_avg_s / 1e12,
+                "algorithmic_ratio": flop_pt * units / kern_avg_s / 1e12 / peak,
+                "hbm_gbps": hbm_gbps, "hbm_frac": hbm_gbps / PEAK_HBM_GBPS,
+                "bytes_per_point": byte_pt,
+                "note": ("bound = the fp64 pipe (matrix = vector = 78.6 TFLOP/s datasheet; they share one "
+                         "pipe on MI355X, profiles/r01_mfma_f64_probe.txt).  achieved/frac = flops EXECUTED "
+                         "(matrix instructions issued after symmetric block-pair folding + phase-A "
+                         "arithmetic) x units / HIP-event kernel time; algorithmic_ratio = SURVEY.md 8d's "
+                         "un-halved count over the same peak (it exceeds 1 because folding halves the "
+                         "variance work); hbm_frac = algorithmic bytes against 8 TB/s")}
         out = {
             "metric": metric,
             "value": value, "unit": "test-points/s", "n_gpus": world, "steps": a.steps,
@@ -402,30 +594,29 @@ def main():
                        "n_emulators": E,
                        "parallelism": "row-sharded x%d, no collective" % world,
                        "device": info["name"], "compute_units": info["compute_units"]},
-            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic,
-                         "kernel": kfull, "kernel_ms": kern_avg_s * 1e3,
-                         "flop_per_point": flop_pt,
-                         "executed": {"flop_per_point": exec_flop_pt, "achieved": executed_tf,
-                                      "frac": executed_tf / peak,
-                                      "what": ("variance MFMAs actually issued (symmetric folding)"
-                                               if kind != "hessian" else
-                                               "pair-product MFMAs actually issued (4 x 4 blocks)" if hess_mfma
-                                               else "pair-product fmas actually issued (upper triangle)")},
-                         "note": ("achieved = algorithmic flop/pt of SURVEY.md 8d (un-halved variance "
-                                  "contraction / Hessian as the reference writes it) x units per launch "
-                                  "/ HIP-event kernel time.  The kernel EXECUTES fewer flops than that "
-                                  "(symmetric block-pair folding of the variance: 0.53x of its MFMAs; "
-                                  "Hessian: D(D+1)/2 products), which is how frac can exceed 1; peak is "
-                                  "the fp64 matrix (= vector) datasheet rate, measured MFMA-only ceiling "
-                                  "on this chip 71.4 TFLOP/s (profiles/r01_mfma_f64_probe.txt)"),
-                         "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                 "frac": hbm_gbps / PEAK_HBM_GBPS, "bytes_per_point": byte_pt}},
-            "parity": dict(zip(names, errs), tol=tol, checked_rows=int(len(idx))),
+            "roofline": roof,
+            "parity": dict(errs, tol=tol, checked_rows=int(n_checked)),
         }
-        if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
-            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and a.workload == "c2" and not a.no_e2e:
+            # host numpy in -> host numpy out through the same library (outside the timed region)
+            for p_ in bufs:
+                ctx.free(p_)
+            bufs = []
+            rate, steady, first = e2e_leg(N, D, M, inputs, testing, theta, invQ, invQt, dtype)
+            roof["e2e_points_per_s"] = rate
+            roof["e2e_ms_per_call"] = steady * 1e3
+            roof["e2e_first_call_ms"] = first * 1e3
+            out["end_to_end"] = {"value": rate, "unit": "test-points/s", "ms_per_call": steady * 1e3,
+                                 "first_call_ms": first * 1e3, "rows": M, "threshold": 2e5,
+                                 "what": "gp.predict(testing, is_gpu=True) from host numpy arrays to host numpy "
+                                         "arrays, median of 10 calls after 3 warm-up calls (PCIe and host copies "
+                                         "included; tests/benchmark.py:41-44)"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            cpu["gpu_over_cpu"] = value / cpu["value"]          # resident GPU rate / reference-style CPU
+            if "end_to_end" in out:
+                cpu["e2e_over_cpu"] = out["end_to_end"]["value"] / cpu["value"]
+                cpu["e2e_over_all_cores"] = out["end_to_end"]["value"] / cpu["all_cores_value"]
         print(json.dumps(out), flush=True)
 
     for p in bufs:

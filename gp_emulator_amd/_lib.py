@@ -239,6 +239,14 @@ class Context:
             check(self.lib.gp_memcpy_d2h(self.h, _ptr(out), dptr, out.nbytes), "gp_memcpy_d2h")
         return out
 
+    def to_host_at(self, dptr, offset_bytes, shape, dtype):
+        """Copy ``shape`` elements starting ``offset_bytes`` into a device buffer (spot checks of
+        results too large to bring back whole)."""
+        out = np.empty(shape, dtype=dtype)
+        src = c_void_p(dptr.value + int(offset_bytes))
+        check(self.lib.gp_memcpy_d2h(self.h, _ptr(out), src, out.nbytes), "gp_memcpy_d2h")
+        return out
+
     def reconstruct_device(self, dtype, d_basis, d_coef, d_out, n_rows, n_pcs, n_bands):
         """out[r][band] = sum_p coef[p][r] * basis[p][band] on the device (asynchronous)."""
         code = GP_F64 if np.dtype(dtype) == np.float64 else GP_F32
@@ -317,8 +325,10 @@ class Model:
     def info(self):
         v = [c_int(0) for _ in range(5)]
         check(self.ctx.lib.gp_model_info(self.h, *[ctypes.byref(x) for x in v]))
+        nk = c_int(0)
+        check(self.ctx.lib.gp_kernel_ksteps(v[1].value, v[2].value, ctypes.byref(nk)))
         return dict(dtype=v[0].value, n_train=v[1].value, n_inputs=v[2].value,
-                    kernel_d=v[3].value, kernel_nb=v[4].value)
+                    kernel_d=v[3].value, kernel_nb=v[4].value, kernel_nk=nk.value)
 
     def predict_device(self, d_testing, d_mu, d_var, d_deriv, n_predict,
                        deriv_layout=GP_DERIV_ROWMAJOR):

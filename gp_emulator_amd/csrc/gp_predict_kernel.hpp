@@ -52,6 +52,13 @@ namespace gpk {
 #ifndef GP_ABLATE
 #define GP_ABLATE 0
 #endif
+#ifndef GP_AHEAD
+// matrix-core phase: A-operand LDS reads in flight (a ring of registers).  A/B on one device
+// (profiles/r02_ab_kernel_variants.txt): 1 (read, wait, issue) 1.452 ms, 2: 1.443, 4: 1.435,
+// 6: 1.435; folding a column block into the variance sum two instructions into the NEXT block
+// (second accumulator) on top of 4: 1.442 -- not kept.  fp32: no difference.
+#define GP_AHEAD 4
+#endif
 #ifndef GP_ESTRIN
 #define GP_ESTRIN 0     // 1: Estrin form of the exp polynomial (A/B: slower, more registers)
 #endif
@@ -602,6 +609,8 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
     // ---------------- phase B: variance on the matrix core -----------------
     T vacc = T(0);
     acc_t acc;
+    constexpr int kAhead = GP_AHEAD;
+    T afr[kAhead];
 #if GP_ABLATE == 1
     static_for<NK>([&](auto qc) { vacc += kv[decltype(qc)::value]; });
     static_for<0>([&](auto fc) {
@@ -617,10 +626,20 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
         __syncthreads();  // chunk c visible; everyone finished reading chunk c-1
         if constexpr (c + 1 < NCH)
           stage_chunk<T>(frags + (c + 1) * kChunk * 64, &s_fr[(c + 1) & 1][0], wave, lane);
+        // the chunk's first A operands (the ring below keeps kAhead - 1 reads in flight)
+        static_for<kAhead - 1>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (j < kChunk && f + j < NF) afr[j % kAhead] = s_fr[c & 1][j * 64 + lane];
+        });
       }
+      // A operands are read kAhead - 1 fragments ahead of their matrix instruction (inside the
+      // chunk: the next chunk becomes readable only behind its barrier), so the LDS latency
+      // hides behind the matrix instructions in between instead of in front of each pair
+      if constexpr (fl + kAhead - 1 < kChunk && f + kAhead - 1 < NF)
+        afr[(fl + kAhead - 1) % kAhead] = s_fr[c & 1][(fl + kAhead - 1) * 64 + lane];
       if constexpr (I == J && s == 0) acc = acc_t{T(0), T(0), T(0), T(0)};
       // (k-steps s >= KL of the last training block are padding: not issued)
-      if constexpr (4 * I + s < NK) acc = R::mfma(s_fr[c & 1][fl * 64 + lane], kv[4 * I + s], acc);
+      if constexpr (4 * I + s < NK) acc = R::mfma(afr[fl % kAhead], kv[4 * I + s], acc);
       if constexpr (I == NB - 1 && s == 3) {
         // rows of the last column block beyond its KL registers are padding too (exactly 0)
 #pragma unroll

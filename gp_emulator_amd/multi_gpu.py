@@ -102,6 +102,44 @@ def predict_sharded(gp, testing, devices, precision=np.float64, predict_fn=None,
     return mu, var, deriv
 
 
+class SharedOutputs:
+    """The gathered result of a one-process-per-GPU run: ONE set of host arrays (mu (M,),
+    var (M,), deriv (M, D), float64) in a file under /dev/shm that every rank maps.  Rank r's
+    predict writes rows [lo, hi) of it directly (``views(lo, hi)`` as ``out=``): the host gather
+    of the north star ("independent row blocks gathered on the host") with no collective and no
+    second copy.  The creating rank sizes the file; the others open it after a barrier."""
+
+    def __init__(self, path, n_rows, n_inputs, create):
+        import mmap
+        self.path, self.M, self.D = path, int(n_rows), int(n_inputs)
+        nbytes = self.M * (2 + self.D) * 8
+        if create:
+            with open(path, "wb") as fh:
+                fh.truncate(nbytes)
+        self._fh = open(path, "r+b")
+        self._mm = mmap.mmap(self._fh.fileno(), nbytes) if nbytes else None
+        whole = np.frombuffer(self._mm, dtype=np.float64) if nbytes else np.empty(0)
+        self.mu, self.var = whole[:self.M], whole[self.M:2 * self.M]
+        self.deriv = whole[2 * self.M:].reshape(self.M, self.D)
+
+    def views(self, lo, hi):
+        return self.mu[lo:hi], self.var[lo:hi], self.deriv[lo:hi]
+
+    def close(self, unlink=False):
+        self.mu = self.var = self.deriv = None
+        try:
+            if self._mm is not None:
+                self._mm.close()
+        except BufferError:          # a caller still holds a view: the mapping goes with it
+            pass
+        self._fh.close()
+        if unlink:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+
 class RankGroup:
     """Barrier + max-reduce over the ranks of a torch.distributed.run launch (gloo).
 

@@ -96,6 +96,60 @@ def test_gloo_world2_barrier_and_max_timing(tmp_path):
     assert out["dt"] >= 5 * 0.02                       # max over ranks: the slow rank's time
 
 
+STRONG_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from gp_emulator_amd import multi_gpu
+from oracle import gp_oracle
+# the strong-scaling flow of bench.py --workload c4 --scaling strong, with the numpy path standing
+# in for the GPU: a FIXED total of rows split over the ranks, every rank writing its shard
+# straight into its slice of ONE shared host array (the host gather; no collective)
+grp = multi_gpu.RankGroup()
+total, D = 3001, 4
+inputs, testing, theta, invQ, invQt = gp_oracle.benchmark_inputs(77, 50, D, total)   # same on every rank
+lo, hi = multi_gpu.row_shards(total, grp.world)[grp.rank]
+path = {path!r}
+shared = multi_gpu.SharedOutputs(path, total, D, create=True) if grp.rank == 0 else None
+grp.barrier()
+if shared is None:
+    shared = multi_gpu.SharedOutputs(path, total, D, create=False)
+out = shared.views(lo, hi)
+def step():
+    out[0][:], out[1][:], out[2][:] = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing[lo:hi])
+dt = multi_gpu.timed_steps(grp, step, lambda: None, steps=2, warmup=1)
+grp.barrier()
+if grp.rank == 0:
+    ref = gp_oracle.cpu_predict(inputs, theta, invQ, invQt, testing)
+    # (BLAS sums a 1501-row block in a different order than a 3001-row one: equal to rounding)
+    err = max(gp_oracle.maxnorm_err(a, b) for a, b in zip(ref, (shared.mu, shared.var, shared.deriv)))
+    print(json.dumps(dict(world=grp.world, err=err, rows=int(hi - lo), dt=dt,
+                          other_ranks_rows_present=bool(np.all(shared.mu[hi:] != 0)))))
+grp.barrier()
+del out
+shared.close(unlink=grp.rank == 0)
+grp.close()
+"""
+
+
+def test_gloo_world2_strong_scaling_host_gather(tmp_path):
+    """Two gloo ranks on the CPU: disjoint row shards of a fixed total written into one shared
+    host array equal the single-process result (rows are independent)."""
+    path = str(tmp_path / "gathered.bin")
+    script = tmp_path / "strong_worker.py"
+    script.write_text(STRONG_WORKER.format(root=ROOT, path=path))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["world"] == 2 and out["rows"] == 1501
+    assert out["err"] <= 1e-12 and out["other_ranks_rows_present"]
+    assert not os.path.exists(path)
+
+
 # ---------------------------------------------------------------------------------------------
 # perband.learn_bands: the request-gathering runtime, driven by a numpy objective (no GPU)
 # ---------------------------------------------------------------------------------------------

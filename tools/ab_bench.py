@@ -17,7 +17,7 @@ for r in range(a.rounds):
     for n, path in vs:
         env = dict(os.environ, GP_PREDICT_LIB=os.path.abspath(path))
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline",
-                              "--steps", "20", "--warmup", "3"] + a.args.split(),
+                              "--no-e2e", "--steps", "20", "--warmup", "3"] + a.args.split(),
                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
