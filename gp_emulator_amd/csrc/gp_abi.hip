@@ -609,12 +609,17 @@ static int ensure_hess_frags(gp_ctx* ctx, gp_model* m) {
   std::lock_guard<std::mutex> lock(m->h_mutex);
   if (m->d_pfrags) return GP_OK;
   const int kd = m->kernel_d, knb = m->kernel_nb, N = m->n_train;
-  const size_t n = (size_t)gpk::hess_frag_count_padded(kd, knb, gpk::Geo<T>::kChunk) * 64;
+  // geometry of hessian_mfma_kernel<T, kd, knb> (gpk::HGeo): wide instances take their
+  // fragments in paired order and in chunks of one pair block
+  const bool wide = gpk::hess_wide<T>(kd, knb);
+  const int chunk = wide ? 4 * knb : gpk::Geo<T>::kChunk;
+  const int nblk = gpk::hess_blocks(kd);
+  const size_t n = (size_t)gpk::hess_frag_count_padded(kd, knb, chunk) * 64;
   std::vector<T> fr(n, T(0));
-  for (int c = 0; c < gpk::hess_blocks(kd); ++c)
+  for (int c = 0; c < nblk; ++c)
     for (int I = 0; I < knb; ++I)
       for (int s = 0; s < 4; ++s) {
-        T* f = fr.data() + (size_t)gpk::hess_frag_index(c, I, s, knb) * 64;
+        T* f = fr.data() + (size_t)gpk::hess_frag_index(c, I, s, knb, wide, nblk) * 64;
         for (int l = 0; l < 64; ++l) {
           const int i = gpk::own_index<T>(I, s, l >> 4);   // slot; padding slots hold zero rows
           const int q = l & 15;             // MFMA output row = accumulator r of lane group g
@@ -652,7 +657,7 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
     h.hess = (T*)d_hess;
     h.M = M;
     h.d_actual = m->n_inputs;
-    constexpr int kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
+    const int kRowsPerWG = gpk::hess_wide<T>(m->kernel_d, m->kernel_nb) ? 4 * gpk::kTile : gpk::Geo<T>::kRowsPerWG;
     const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG;
     int64_t grid = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU;
     if (grid > groups) grid = groups;

@@ -24,12 +24,26 @@
 // which the compiler-scheduled VALU loop only fills to ~50 %.  The pairs are taken in 4 x 4 blocks
 // of the matrix (160 products instead of 136 at D = 16, 96 instead of 66 at D = 11).
 //
+// Two geometries.  The standard one is predict_kernel's (fp64: 8 waves, two per SIMD, 256 registers
+// each).  The fp64 weight tile alone is 8 NB registers (152 at N = 300), and with t'', G and a
+// training row beside it phase A of the larger instances does not fit 256: they spilled up to 141
+// registers and had to give up the 16-byte stores.  Those instances (hess_wide) run ONE wave per
+// SIMD with the whole 512-register file (4 waves of 16 rows per workgroup): the weights sit in the
+// accumulation half, which the matrix instructions read as B operands directly, nothing spills,
+// and every path stores 16 bytes.  A single wave's dependent chain of fp64 matrix instructions
+// reaches 79 % of the pipe and two interleaved chains 85 % (tools/mfma_f64_probe.hip), so the
+// wide kernel works on two pair blocks at a time, their fragments interleaved in the packed
+// buffer (hess_frag_index, paired order).
+//
 // Accuracy: the expansion cancels like predict_kernel's exp(h_i + g + x''.t'') does -- by about
 // (|x''| + |t''|)^2 / |x'' - t''|^2, small because the coordinates are centred on the training
 // mean; fp64 stays at 1e-15 on the benchmark sets (tests).
 #pragma once
 #include "gp_predict_kernel.hpp"
 
+#ifndef GP_HESS_GROUP
+#define GP_HESS_GROUP 4
+#endif
 #ifndef GP_HESSM_ABLATE
 #define GP_HESSM_ABLATE 0
 #endif
@@ -51,8 +65,23 @@ __host__ __device__ constexpr int hess_block_bj(int c) {
   return bj;
 }
 __host__ __device__ constexpr int hess_block_bi(int c) { return c - hess_block_bj(c) * (hess_block_bj(c) + 1) / 2; }
-// fragment (block c, training block I, k-step s) in consumption order
-__host__ __device__ constexpr int hess_frag_index(int c, int I, int s, int NB) { return (c * NB + I) * 4 + s; }
+// Instances that run one wave per SIMD with 512 registers (see the header comment).
+template <typename T> __host__ __device__ constexpr bool hess_wide(int D, int NB) {
+  return sizeof(T) == 8 && (NB >= 16 || (NB >= 12 && D >= 16));
+}
+// fragment (block c, training block I, k-step s) in consumption order.  Plain order: block after
+// block.  Paired order (wide kernels): blocks 2p and 2p + 1 alternate fragment by fragment, so
+// two independent accumulator chains are in flight; an odd last block comes alone.
+__host__ __device__ constexpr int hess_frag_index(int c, int I, int s, int NB, bool paired = false, int nblk = 0) {
+  if (!paired || (c == nblk - 1 && (nblk & 1))) return (c * NB + I) * 4 + s;
+  return (c / 2) * 8 * NB + (I * 4 + s) * 2 + (c & 1);
+}
+struct HessFragId { int c, I, s; };
+__host__ __device__ constexpr HessFragId hess_frag_at(int n, int NB, bool paired, int nblk) {
+  if (!paired || n >= (nblk / 2) * 8 * NB) return HessFragId{n / (4 * NB), (n / 4) % NB, n % 4};
+  const int p = n / (8 * NB), r = n % (8 * NB);
+  return HessFragId{2 * p + (r & 1), (r / 2) / 4, (r / 2) % 4};
+}
 __host__ __device__ constexpr int hess_frag_count(int D, int NB) { return hess_blocks(D) * NB * 4; }
 __host__ __device__ constexpr int hess_frag_count_padded(int D, int NB, int chunk) {
   return (hess_frag_count(D, NB) + chunk - 1) / chunk * chunk;
@@ -132,18 +161,37 @@ struct HessMfmaArgs {
   int d_actual;
 };
 
+// Geometry of hessian_mfma_kernel<T, D, NB> (see the header comment).
+template <typename T, int D, int NB> struct HGeo {
+  static constexpr bool kWide = hess_wide<T>(D, NB);
+  static constexpr int kWaves = kWide ? 4 : Geo<T>::kWaves;
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr int kWavesPerSimd = kWide ? 1 : Geo<T>::kWavesPerSimd;
+  static constexpr int kRowsPerWG = kWaves * kTile;
+  // A-operand fragments per LDS chunk.  Wide: one pair block's worth (4 NB), so that a chunk
+  // boundary -- whose s_waitcnt vmcnt(0) also waits for the wave's outstanding global stores --
+  // always comes a whole block after the previous block's stores were issued.
+  static constexpr int kChunk = kWide ? 4 * NB : Geo<T>::kChunk;
+  static constexpr int kGroup = kWide ? GP_HESS_GROUP : 1;     // training points in flight in phase A
+  static constexpr int kAccs = kWide ? 4 : 2;      // accumulators (blocks alternate; wide: pairs)
+};
+
 template <typename T, int D, int NB>
-__global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void hessian_mfma_kernel(HessMfmaArgs<T> p) {
+__global__ __launch_bounds__((HGeo<T, D, NB>::kThreads), (HGeo<T, D, NB>::kWavesPerSimd))
+void hessian_mfma_kernel(HessMfmaArgs<T> p) {
   typedef Real<T> R;
   typedef typename R::acc_t acc_t;
-  constexpr int kThreads = Geo<T>::kThreads;
-  constexpr int kWaves = Geo<T>::kWaves;
-  constexpr int kRowsPerWG = Geo<T>::kRowsPerWG;
+  typedef HGeo<T, D, NB> G;
+  constexpr bool kWide = G::kWide;
+  constexpr int kThreads = G::kThreads;
+  constexpr int kWaves = G::kWaves;
+  constexpr int kRowsPerWG = G::kRowsPerWG;
   constexpr int NP = 16 * NB;
   constexpr int DS = row_stride(D);
   constexpr int NB4 = hess_nb4(D);
+  constexpr int NBLK = hess_blocks(D);
   constexpr int NF = hess_frag_count(D, NB);
-  constexpr int kChunk = Geo<T>::kChunk;
+  constexpr int kChunk = G::kChunk;
   constexpr int NCH = (NF + kChunk - 1) / kChunk;
 
   __shared__ __attribute__((aligned(16))) T s_xa[NP * DS];
@@ -168,20 +216,38 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void hessi
   for (int j = 0; j < NB4; ++j) sdq[j] = (4 * j + g < D) ? s_sd[4 * j + g] : T(0);
 
   const long long n_groups = (p.M + kRowsPerWG - 1) / kRowsPerWG;
+  // the lane's raw test row: loaded one item ahead (wide kernels: a lone wave per SIMD has
+  // nothing else to hide the HBM latency of these loads behind; they land during phase A)
+  T rraw[D];
+  auto load_row = [&](long long grp_) {
+    const long long m_ = grp_ * kRowsPerWG + wave * kTile + ml;
+    const long long mc_ = m_ < p.M ? m_ : p.M - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int dc = d < p.d_actual ? d : p.d_actual - 1;     // padded dims: sd = centre = 0
+      rraw[d] = p.testing[mc_ * p.d_actual + dc];
+    }
+  };
+  if constexpr (kWide)
+    if ((long long)blockIdx.x < n_groups) load_row(blockIdx.x);
   for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const long long m = grp * kRowsPerWG + wave * kTile + ml;
     const long long mc = m < p.M ? m : p.M - 1;
     __syncthreads();            // previous item's readers of s_fr[0] are done
-    stage_chunk<T>(p.pfrags, &s_fr[0][0], wave, lane);
+    stage_chunk<T, kWaves, kChunk>(p.pfrags, &s_fr[0][0], wave, lane);
 
     // ---------------- phase A: weight tile, s, G ----------------------------------------
     T t[D];
     T gm = T(0);
+    if constexpr (!kWide) load_row(grp);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const int dc = d < p.d_actual ? d : p.d_actual - 1;     // padded dims: sd = centre = 0
-      t[d] = s_sd[d] * (p.testing[mc * p.d_actual + dc] - s_sd[D + d]);
+      t[d] = s_sd[d] * (rraw[d] - s_sd[D + d]);
       gm = fma(t[d], t[d], gm);
+    }
+    if constexpr (kWide) {
+      asm volatile("" :: "v"(gm));       // (the loads below stay below the uses above)
+      load_row(grp + gridDim.x < n_groups ? grp + gridDim.x : grp);
     }
     gm *= T(-0.5);
     const T poison = gm - gm;   // NaN for rows holding a NaN or an infinity (exp_ clamps)
@@ -190,33 +256,58 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void hessi
     T ga[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) ga[d] = T(0);
-    static_for<4 * NB>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      const int i = own_index<T>(q >> 2, q & 3, g);
-      const T* row = &s_xa[i * DS];
-      T x[D];
+    // (wide kernels: two training points at a time, their serial chains interleave)
+    constexpr int GP = G::kGroup;
+    static_assert((4 * NB) % GP == 0, "group size must divide the points per lane");
+    static_for<4 * NB / GP>([&](auto qc) {
+      constexpr int q0 = decltype(qc)::value * GP;
+      T x[GP][D];
+      T al[GP], k[GP];
 #pragma unroll
-      for (int d = 0; d < D; ++d) x[d] = row[d];
-      T k;
+      for (int u = 0; u < GP; ++u) {
+        const int q = q0 + u;
+        const int i = own_index<T>(q >> 2, q & 3, g);
+        const T* row = &s_xa[i * DS];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[u][d] = row[d];
+        al[u] = row[D];
+        if constexpr (R::kExpand) k[u] = row[D + 1] + gm;
+      }
+      // dimension by dimension across the group: GP dependency chains side by side
       if constexpr (R::kExpand) {
-        k = row[D + 1] + gm;
-#pragma unroll
-        for (int d = 0; d < D; ++d) k = fma(x[d], t[d], k);
-        k = R::exp_(k);
-      } else {
-        T r2 = T(0);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          const T dl = x[d] - t[d];
-          r2 = fma(dl, dl, r2);
-        }
-        k = b * R::exp_(T(-0.5) * r2);
-      }
-      const T w = k * row[D];
-      kv[q] = w;
-      mu += w;
 #pragma unroll
-      for (int d = 0; d < D; ++d) ga[d] = fma(w, x[d], ga[d]);
+          for (int u = 0; u < GP; ++u) k[u] = fma(x[u][d], t[d], k[u]);
+        }
+      } else {
+        T r2[GP];
+#pragma unroll
+        for (int u = 0; u < GP; ++u) r2[u] = T(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+          for (int u = 0; u < GP; ++u) {
+            const T dl = x[u][d] - t[d];
+            r2[u] = fma(dl, dl, r2[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GP; ++u) k[u] = T(-0.5) * r2[u];
+      }
+      R::template exp_n<GP>(k);
+      if constexpr (!R::kExpand) {
+#pragma unroll
+        for (int u = 0; u < GP; ++u) k[u] *= b;
+      }
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        const T w = k[u] * al[u];
+        kv[q0 + u] = w;
+        mu += w;
+#pragma unroll
+        for (int d = 0; d < D; ++d) ga[d] = fma(w, x[u][d], ga[d]);
+      }
     });
     mu = xor_reduce_groups(mu) + poison;
     static_for<(D + 5) / 6>([&](auto bc) {
@@ -225,7 +316,8 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void hessi
       xor_reduce_groups_n<T, nb_>(&ga[d0]);
     });
     // The epilogue needs t''_d, G_d for a compile-time d (read back from the wave's LDS slot,
-    // which frees 4 D registers during the matrix phase) and for d2 = 4 bj + g (kept per lane).
+    // which frees 4 D registers during the matrix phase; keeping them in registers in the wide
+    // kernels measured 0.7 % slower) and for d2 = 4 bj + g (kept per lane).
     // Lane group g writes the dimensions d = g (mod 4) -- after the reduction all four agree.
     T tq[NB4], gq[NB4];
 #pragma unroll
@@ -243,10 +335,10 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void hessi
     T* out = p.hess + mc * (long long)p.d_actual * p.d_actual;
     const bool row_ok = m < p.M;
     // 16-byte stores need rows that are whole vectors and an aligned matrix (uniform condition).
-    // The largest fp64 instances (D = 16 with N > 192: 152 registers of weights alone) are over
-    // the register budget already; the transposed copy costs them more in spills than the wider
-    // stores give back (3.27e8 vs 3.44e8 rows/s at N = 300), so they keep the 8-byte stores.
-    constexpr bool kVecStores = !(sizeof(T) == 8 && D > 12 && NB > 12);
+    // The standard-geometry fp64 instances that are over their 256 registers keep 8-byte stores
+    // (the transposed copy costs them more in spills than the wider stores give back); the large
+    // ones run wide and store 16 bytes like everything else.
+    constexpr bool kVecStores = kWide || !(sizeof(T) == 8 && D > 12 && NB > 12);
     const bool vec_ok = kVecStores && (p.d_actual % (16 / (int)sizeof(T)) == 0) &&
                         (((unsigned long long)p.hess & 15) == 0);
     // Finish and store block `cbv` from its accumulator: acc[r] = S2[d][d2] for d = 4 bi + r,
@@ -310,31 +402,52 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void hessi
 #endif
 #endif
     };
-    // Two accumulators alternate between consecutive blocks, and a block is finished a few MFMAs
-    // into the NEXT block: its last MFMA has retired by then and the epilogue's VALU and LDS
-    // work issues between matrix instructions instead of behind a drained pipe.
-    acc_t accs[2];
-    constexpr int kLag = (NB > 2) ? 2 : NB - 1;       // training block of the next pair block
+    // Blocks are worked in groups -- one block (standard) or a pair whose fragments alternate
+    // (wide: two independent accumulator chains) -- on alternating accumulators, and a group is
+    // finished a few matrix instructions into the NEXT group: its last instruction has retired
+    // by then and the epilogue's VALU and LDS work issues between matrix instructions instead of
+    // behind a drained pipe.
+    constexpr int kAccs = G::kAccs;
+    constexpr int kPer = kWide ? 2 : 1;                 // blocks per group
+    constexpr int NGRP = (NBLK + kPer - 1) / kPer;
+    acc_t accs[kAccs];
+    constexpr int kLag = (NB > 2) ? 2 : NB - 1;         // training block of the next group
+    constexpr int kAhead = GP_AHEAD;
+    T afr[kAhead];
+    auto finish_group = [&](auto gc) {
+      constexpr int gv = decltype(gc)::value;
+      static_for<kPer>([&](auto jc) {
+        constexpr int cbv = gv * kPer + decltype(jc)::value;
+        if constexpr (cbv < NBLK) finish_block(std::integral_constant<int, cbv>{}, accs[cbv % kAccs]);
+      });
+    };
     static_for<NF>([&](auto fc) {
       constexpr int f = decltype(fc)::value;
       constexpr int ch = f / kChunk, fl = f % kChunk;
-      constexpr int cb = f / (4 * NB), I = (f / 4) % NB, s = f % 4;
+      constexpr HessFragId fid = hess_frag_at(f, NB, kWide, NBLK);
+      constexpr int cb = fid.c, I = fid.I, s = fid.s;
       if constexpr (fl == 0) {
         dma_wait();       // this wave's pieces of chunk ch have landed
         __syncthreads();  // chunk ch visible; everyone finished reading chunk ch-1
         if constexpr (ch + 1 < NCH)
-          stage_chunk<T>(p.pfrags + (ch + 1) * kChunk * 64, &s_fr[(ch + 1) & 1][0], wave, lane);
+          stage_chunk<T, kWaves, kChunk>(p.pfrags + (ch + 1) * kChunk * 64, &s_fr[(ch + 1) & 1][0], wave, lane);
+        static_for<kAhead - 1>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (j < kChunk && f + j < NF) afr[j % kAhead] = s_fr[ch & 1][j * 64 + lane];
+        });
       }
-      if constexpr (I == 0 && s == 0) accs[cb & 1] = acc_t{T(0), T(0), T(0), T(0)};
+      if constexpr (fl + kAhead - 1 < kChunk && f + kAhead - 1 < NF)
+        afr[(fl + kAhead - 1) % kAhead] = s_fr[ch & 1][(fl + kAhead - 1) * 64 + lane];
+      if constexpr (I == 0 && s == 0) accs[cb % kAccs] = acc_t{T(0), T(0), T(0), T(0)};
 #if GP_HESSM_ABLATE == 3   // diagnostic: no matrix instructions (one fma keeps the operands alive)
-      if constexpr (s == 0 && I == 0) accs[cb & 1][0] = fma(s_fr[ch & 1][fl * 64 + lane], kv[4 * I + s], accs[cb & 1][0]);
+      if constexpr (s == 0 && I == 0) accs[cb % kAccs][0] = fma(afr[fl % kAhead], kv[4 * I + s], accs[cb % kAccs][0]);
 #else
-      accs[cb & 1] = R::mfma(s_fr[ch & 1][fl * 64 + lane], kv[4 * I + s], accs[cb & 1]);
+      accs[cb % kAccs] = R::mfma(afr[fl % kAhead], kv[4 * I + s], accs[cb % kAccs]);
 #endif
-      if constexpr (cb > 0 && I == kLag && s == 0)
-        finish_block(std::integral_constant<int, cb - 1>{}, accs[(cb - 1) & 1]);
+      if constexpr (cb % kPer == 0 && cb >= kPer && I == kLag && s == 0)
+        finish_group(std::integral_constant<int, cb / kPer - 1>{});
     });
-    finish_block(std::integral_constant<int, hess_blocks(D) - 1>{}, accs[(hess_blocks(D) - 1) & 1]);
+    finish_group(std::integral_constant<int, NGRP - 1>{});
   }
 }
 

@@ -11,7 +11,7 @@ namespace gpk {
 
 template <int D>
 static hipError_t launch_one(const HessMfmaArgs<GP_T>& a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((hessian_mfma_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(Geo<GP_T>::kThreads), 0, stream, a);
+  hipLaunchKernelGGL((hessian_mfma_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(HGeo<GP_T, D, GP_NB>::kThreads), 0, stream, a);
   return hipGetLastError();
 }
 

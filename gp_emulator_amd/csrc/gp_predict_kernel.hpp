@@ -162,6 +162,33 @@ template <> struct Real<double> {
 #endif
     return ldexp(p, (int)n);
   }
+  // exp_ of GP values, written step by step across the values: GP independent dependency chains
+  // side by side in program order (for kernels that run one wave per SIMD, where nothing else
+  // hides the latency of a dependent fp64 instruction)
+  template <int GP>
+  __device__ static inline void exp_n(double (&x)[GP]) {
+    double n[GP], r[GP], p[GP];
+#pragma unroll
+    for (int u = 0; u < GP; ++u) x[u] = __builtin_fmax(x[u], -1000.0);
+#pragma unroll
+    for (int u = 0; u < GP; ++u) n[u] = __builtin_rint(x[u] * 1.4426950408889634);
+#pragma unroll
+    for (int u = 0; u < GP; ++u) r[u] = fma(n[u], -6.93147180559945286e-01, x[u]);
+#pragma unroll
+    for (int u = 0; u < GP; ++u) r[u] = fma(n[u], -2.31904681384629956e-17, r[u]);
+#pragma unroll
+    for (int u = 0; u < GP; ++u) p[u] = 2.76263485910095559e-07;
+    constexpr double c[10] = {2.76401812311866076e-06, 2.48015043709117912e-05, 1.98411702695461072e-04,
+                              1.38888889324666632e-03, 8.33333338566834801e-03, 4.16666666665732183e-02,
+                              1.66666666665544028e-01, 5.00000000000000555e-01, 1.00000000000000666e+00, 1.0};
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+#pragma unroll
+      for (int u = 0; u < GP; ++u) p[u] = fma(p[u], r[u], c[j]);
+    }
+#pragma unroll
+    for (int u = 0; u < GP; ++u) x[u] = ldexp(p[u], (int)n[u]);
+  }
 };
 template <> struct Real<float> {
   typedef f32x4 acc_t;
@@ -179,6 +206,11 @@ template <> struct Real<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   __device__ static inline float exp_(float x) { return __expf(x); }
+  template <int GP>
+  __device__ static inline void exp_n(float (&x)[GP]) {
+#pragma unroll
+    for (int u = 0; u < GP; ++u) x[u] = __expf(x[u]);
+  }
 };
 
 // Training index that lane group g pairs with k-step s of 16-block I.
@@ -315,12 +347,10 @@ __device__ inline T xor_reduce_groups(T v) {
 // M0 (the DMA's LDS base) is compiler-reserved and not preserved around an asm statement, and
 // it cannot be listed as a clobber: the statement that reads it also writes it, and puts the
 // previous value back before it ends (cdna_hip_programming.md 5.7, "Operands and clobbers").
-template <typename T>
+template <typename T, int kWaves = Geo<T>::kWaves, int kChunk = Geo<T>::kChunk>
 __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int lane) {
-  constexpr int kChunk = Geo<T>::kChunk;
   constexpr int kBytes = kChunk * 64 * (int)sizeof(T);
   constexpr int kPieces = kBytes / 1024;          // 1 KiB per wave-instruction
-  constexpr int kWaves = Geo<T>::kWaves;
   static_assert(kPieces * 1024 == kBytes, "chunk must be whole 1 KiB pieces");
   // wave-uniform SGPR source base, 32-bit per-lane VGPR offset (saddr form); piece pc goes
   // to wave (pc mod kWaves)
