@@ -260,7 +260,7 @@ def bench_train(a):
     for _ in range(a.steps):
         cost, grad = ctx.likelihood_batch(thetas, inputs, targets)
     dt = (time.perf_counter() - t0) / a.steps
-    n_pass = (N + 7) // 8 + 2
+    mfma_flop = ((N + 7) // 8) * 136 * 2 * 2048     # matrix-core flops of one evaluation (N <= 256)
     n_cpu = min(8, E)
     t1 = time.perf_counter()
     for e in range(n_cpu):
@@ -276,13 +276,15 @@ def bench_train(a):
            "config": {"workload": "training objective for %d per-band emulators (N_train=250, D=10): cost, "
                                   "gradient, invQ, invQt per theta; host arrays in and out" % E,
                       "device": info["name"]},
-           "roofline": {"bound": "hbm", "achieved": E * n_pass * 2 * N * N * 8 / dt / 1e9, "peak": PEAK_HBM_GBPS,
-                        "unit": "GB/s", "frac": E * n_pass * 2 * N * N * 8 / dt / 1e9 / PEAK_HBM_GBPS,
-                        "traffic": None, "kernel": "likelihood_kernel",
-                        "note": "Gauss-Jordan, 8 pivots per pass: the N x N workspace is read and written "
-                                "ceil(N/8) + 2 times per theta (build, passes, gradient), 2 N^2 x 8 B each, "
-                                "mostly from the Infinity Cache; achieved = those bytes / wall time "
-                                "(host copies included)"},
+           "roofline": {"bound": "mfma", "achieved": E * mfma_flop / dt / 1e12, "peak": PEAK_FP64_TFLOPS,
+                        "unit": "TFLOP/s", "frac": E * mfma_flop / dt / 1e12 / PEAK_FP64_TFLOPS,
+                        "traffic": None, "kernel": "likelihood_mfma_kernel<12>",
+                        "executed_flop_per_theta": mfma_flop,
+                        "note": "register-resident Gauss-Jordan (gp_train_mfma_kernel.hpp): ceil(N/8) passes x 136 "
+                                "lower-triangle tiles x 2 fp64 matrix instructions of 2048 flop; achieved = those flops / "
+                                "wall time of the whole evaluation (Q build, panel steps, invQt, gradient and the host "
+                                "copies of theta / cost / gradient included) -- the evaluation is bound by the serial "
+                                "panel steps and barriers of each pass, not by the matrix pipe"},
            "cpu_baseline": {"value": 1.0 / cpu_per, "unit": "theta-evaluations/s", "cores": int(os.cpu_count() or 1),
                             "kind": "port", "sample": "%d evaluations of the numpy path (oracle)" % n_cpu},
            "parity": {"checked_sets": n_cpu, "tol_cost": 1e-8, "tol_grad": 1e-5}}

@@ -1284,6 +1284,8 @@ int gp_likelihood_batch_f64(gp_ctx* ctx, int n_sets, const double* theta, const 
   a.targets_stride = targets_shared ? 0 : (long long)N;
   a.work = d_work; a.invQt = d_qt; a.cost = d_cost; a.grad = d_grad;
   a.N = n_train; a.D = n_inputs;
+  a.full_inverse = invQ != nullptr;
+  a.dbg = (unsigned long long*)ctx->dbg;
   hipError_t e = gpk::launch_likelihood(a, n_sets, st);
   if (e != hipSuccess) return fail(GP_ERR_HIP, "likelihood kernel launch: %s", hipGetErrorString(e));
   HIP_TRY(hipMemcpyAsync(cost, d_cost, sizeof(double) * n_cost, hipMemcpyDeviceToHost, st));

@@ -24,6 +24,9 @@ struct TrainArgs {
   double* cost;            // [E]
   double* grad;            // [E][D + 2]
   int N, D;
+  int full_inverse;        // 1: `work` must hold the whole invQ (the caller reads it); 0: likelihood_mfma_kernel
+                           // writes the lower triangle only (all that invQt and the gradient need)
+  unsigned long long* dbg;   // -DGP_TRAIN_STAMPS=1 builds only (tools/train_stamps.py): [8] cycle sums; else unused
 };
 
 // dynamic LDS of one workgroup: pivot rows, W, transposed inputs

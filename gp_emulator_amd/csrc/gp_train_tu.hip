@@ -1,5 +1,8 @@
-// likelihood_kernel launcher (fp64 only).
+// likelihood kernels' launcher (fp64 only).
+#include <cstdlib>
+
 #include "gp_train_kernel.hpp"
+#include "gp_train_mfma_kernel.hpp"
 
 namespace gpk {
 
@@ -14,9 +17,23 @@ hipError_t launch_likelihood(const TrainArgs& a, int n_sets, hipStream_t stream)
   const size_t lds = likelihood_lds_bytes(a.N, a.D);
   const size_t lds_grad = sizeof(double) * (size_t)a.N * a.D;
   const dim3 grid(n_sets), block(tkSide, tkSide);
-  hipError_t e = allow_lds(likelihood_kernel, lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(likelihood_kernel, grid, block, lds, stream, a);
+  hipError_t e = hipSuccess;
+  // n_train <= 256: the register-resident matrix-core elimination (gp_train_mfma_kernel.hpp);
+  // larger sets, or GP_TRAIN_GENERIC=1 (A/B switch): the workspace kernel
+  static const bool generic = [] { const char* ev = getenv("GP_TRAIN_GENERIC"); return ev && atoi(ev) != 0; }();
+  if (a.N <= tmNP && !generic) {
+#define GP_LIK(DM) hipLaunchKernelGGL(likelihood_mfma_kernel<DM>, grid, dim3(tmThreads), 0, stream, a)
+    if (a.D <= 4) GP_LIK(4);
+    else if (a.D <= 8) GP_LIK(8);
+    else if (a.D <= 12) GP_LIK(12);
+    else GP_LIK(tkMaxD);
+#undef GP_LIK
+    return hipGetLastError();            // (the gradient is part of that kernel)
+  } else {
+    e = allow_lds(likelihood_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(likelihood_kernel, grid, block, lds, stream, a);
+  }
   if ((e = hipGetLastError()) != hipSuccess) return e;
 #define GP_GRAD(DM)                                                                  \
   do {                                                                               \
