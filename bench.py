@@ -371,6 +371,10 @@ def bench_strong(a, grp):
     lo, hi = multi_gpu.row_shards(total, world)[rank]
     M = hi - lo
     dtype = np.float64 if a.precision == "f64" else np.float32
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
+    near = _lib.bind_near_device(grp.local_rank % ndev)      # before the shard's rows are generated
     inputs, _, theta, invQ, invQt = synthetic_inputs(1000, N, D, 1)
     testing = np.empty((M, D))
     for s0 in range(0, M, 1 << 20):                    # per-shard seeded generation, bounded temporaries
@@ -383,9 +387,6 @@ def bench_strong(a, grp):
     if rank != 0:
         shared = multi_gpu.SharedOutputs(path, total, D, create=False)
     out = shared.views(lo, hi)
-    ndev = _lib.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
     ctx = _lib.Context(grp.local_rank % ndev)
     info = ctx.device_info()
     model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, dtype)
@@ -415,7 +416,8 @@ def bench_strong(a, grp):
                                    "(host gather, no collective), predict mean+var+grad" % (total, world, M),
                        "n_train": N, "n_inputs": D, "n_test_total": total, "n_test_per_gpu": M,
                        "parallelism": "row-sharded x%d, host gather, no collective" % world,
-                       "device": info["name"], "host_threads_per_rank": ctx.host_threads()},
+                       "device": info["name"], "host_threads_per_rank": ctx.host_threads(),
+                       "cpus_bound_near_gpu": len(near)},
             "roofline": {"bound": "hbm", "achieved": value * 192 / 1e9, "peak": PEAK_HBM_GBPS * world, "unit": "GB/s",
                          "frac": value * 192 / 1e9 / (PEAK_HBM_GBPS * world), "traffic": None,
                          "kernel": "predict_kernel<%s,11,75> behind the host slab pipeline" % ("double" if a.precision == "f64" else "float"),
@@ -460,6 +462,9 @@ def main():
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
+    # one process per GPU: run on the cpus next to that GPU (numactl --cpunodebind by hand), so the
+    # arrays generated below are first-touched on the socket the device's PCIe root belongs to
+    near = _lib.bind_near_device(grp.local_rank % ndev)
     ctx = _lib.Context(grp.local_rank % ndev)
     info = ctx.device_info()
 
@@ -595,7 +600,8 @@ def main():
             "config": {"workload": desc, "n_train": N, "n_inputs": D, "n_test_per_gpu": M,
                        "n_emulators": E,
                        "parallelism": "row-sharded x%d, no collective" % world,
-                       "device": info["name"], "compute_units": info["compute_units"]},
+                       "device": info["name"], "compute_units": info["compute_units"],
+                       "cpus_bound_near_gpu": len(near)},
             "roofline": roof,
             "parity": dict(errs, tol=tol, checked_rows=int(n_checked)),
         }

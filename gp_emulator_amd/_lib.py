@@ -54,6 +54,7 @@ SIGNATURES = {
     "gp_predict_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_i64, c_int, c_i64]),
     "gp_ctx_host_threads": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "gp_device_numa_node": (c_int, [c_int, ctypes.POINTER(c_int)]),
     "gp_kernel_ksteps": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "gp_hessian_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
     "gp_hessian_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
@@ -129,6 +130,36 @@ def device_count():
 
 def _ptr(a):
     return a.ctypes.data_as(c_void_p)
+
+
+def device_numa_cpus(device=0):
+    """The cpus of the NUMA node ``device`` is attached to that this process may run on (empty
+    set when sysfs does not tell).  Initialises the HIP runtime."""
+    node = c_int(-1)
+    if load().gp_device_numa_node(int(device), ctypes.byref(node)) != 0 or node.value < 0:
+        return set()
+    try:
+        text = open("/sys/devices/system/node/node%d/cpulist" % node.value).read().strip()
+    except OSError:
+        return set()
+    cpus = set()
+    for part in text.split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus & set(os.sched_getaffinity(0))
+
+
+def bind_near_device(device=0):
+    """Restrict the calling process to the cpus next to ``device`` (what ``numactl
+    --cpunodebind`` would do for a one-process-per-GPU launch): arrays it allocates afterwards
+    are first-touched on the socket whose PCIe root the device hangs off, so neither the
+    staging copies nor the DMA cross the socket interconnect.  Returns the cpu set used (empty:
+    nothing changed)."""
+    cpus = device_numa_cpus(device)
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    return cpus
 
 
 class OutputPool:

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -717,6 +718,44 @@ static int ensure_scratch(gp_ctx* ctx, size_t bytes) {
 // itself instead of H2D / D2H copies (4.1 ms), one stream per copy direction (no change),
 // pre-touching or huge-page advice for fresh output arrays (no gain; see _lib.OutputPool).
 // GP_HOST_TRACE=1 prints where a call's time went (event waits / host copies / enqueue).
+// NUMA node the device hangs off (sysfs, by PCI bus id); -1 when it cannot be told.
+static int device_numa_node(int device) {
+  char bdf[64] = "";
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return -1;
+  for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE* fh = fopen(path, "r");
+  if (!fh) return -1;
+  int node = -1;
+  if (fscanf(fh, "%d", &node) != 1) node = -1;
+  fclose(fh);
+  return node;
+}
+// the cpus of that node that this process may run on (empty set: unknown / none)
+static bool node_cpus(int node, cpu_set_t* out) {
+  CPU_ZERO(out);
+  if (node < 0) return false;
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* fh = fopen(path, "r");
+  if (!fh) return false;
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) { fclose(fh); return false; }
+  int a, b, n = 0;
+  while (fscanf(fh, "%d", &a) == 1) {
+    b = a;
+    int ch = fgetc(fh);
+    if (ch == '-') { if (fscanf(fh, "%d", &b) != 1) break; ch = fgetc(fh); }
+    for (int c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &allowed)) { CPU_SET(c, out); ++n; }
+    if (ch != ',') break;
+  }
+  fclose(fh);
+  return n > 0;
+}
+
 static int host_threads() {
   static int n = [] {
     int avail = 1;
@@ -731,8 +770,16 @@ static int host_threads() {
   return n;
 }
 
+// The helper threads run on the cpus of the device's NUMA node (when sysfs tells and the process
+// may use them; GP_HOST_PIN=0 turns it off): the pinned staging buffers they copy into and out of
+// are then allocated and touched next to the PCIe root the DMA goes through.
 static gph::ThreadPool& host_pool(gp_ctx* ctx) {
-  if (!ctx->pipe.pool) ctx->pipe.pool.reset(new gph::ThreadPool(host_threads()));
+  if (!ctx->pipe.pool) {
+    cpu_set_t cpus;
+    const char* ev = getenv("GP_HOST_PIN");
+    const bool pin = (!ev || atoi(ev) != 0) && node_cpus(device_numa_node(ctx->device), &cpus);
+    ctx->pipe.pool.reset(new gph::ThreadPool(host_threads(), pin ? &cpus : nullptr));
+  }
   return *ctx->pipe.pool;
 }
 
@@ -754,11 +801,23 @@ static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
   }
   // grow-only; a size is recorded only after every slot's buffer exists, so a failed
   // allocation can never leave a stale size beside a null buffer
+  // (pinned staging is allocated by a helper thread, i.e. on the device's NUMA node when the
+  // helpers are pinned there -- the calling thread may sit on the other socket)
+  auto host_alloc = [&](void** slot, size_t bytes) -> hipError_t {
+    hipError_t err = hipSuccess;
+    const int dev = ctx->device;
+    host_pool(ctx).run_on_worker([&] {
+      err = hipSetDevice(dev);
+      if (err == hipSuccess) err = hipHostMalloc(slot, bytes, hipHostMallocDefault);
+      if (err == hipSuccess) std::memset(*slot, 0, bytes);       // first touch
+    });
+    return err;
+  };
   if (pp.stage_in_bytes < in_bytes) {
     pp.stage_in_bytes = 0;
     for (int k = 0; k < kPipeSlots; ++k) {
       if (pp.stage_in[k]) { void* q = pp.stage_in[k]; pp.stage_in[k] = nullptr; HIP_TRY(hipHostFree(q)); }
-      HIP_TRY(hipHostMalloc(&pp.stage_in[k], in_bytes, hipHostMallocDefault));
+      HIP_TRY(host_alloc(&pp.stage_in[k], in_bytes));
     }
     pp.stage_in_bytes = in_bytes;
   }
@@ -766,7 +825,7 @@ static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
     pp.stage_out_bytes = 0;
     for (int k = 0; k < kPipeSlots; ++k) {
       if (pp.stage_out[k]) { void* q = pp.stage_out[k]; pp.stage_out[k] = nullptr; HIP_TRY(hipHostFree(q)); }
-      HIP_TRY(hipHostMalloc(&pp.stage_out[k], out_bytes, hipHostMallocDefault));
+      HIP_TRY(host_alloc(&pp.stage_out[k], out_bytes));
     }
     pp.stage_out_bytes = out_bytes;
   }
@@ -1164,6 +1223,12 @@ int gp_hessian_host(gp_ctx* ctx, const gp_model* model, const void* testing, voi
     return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
   if (model->dtype == GP_F64) return hessian_host_model<double>(ctx, model, (const double*)testing, (double*)hess, n_predict);
   return hessian_host_model<float>(ctx, model, (const float*)testing, (float*)hess, n_predict);
+}
+
+int gp_device_numa_node(int device, int* node) {
+  if (!node) return fail(GP_ERR_INVALID, "null pointer");
+  *node = device_numa_node(device);
+  return GP_OK;
 }
 
 int gp_ctx_host_threads(gp_ctx* ctx, int* n_threads) {

@@ -13,7 +13,11 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
+
+#include <pthread.h>
+#include <sched.h>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -29,9 +33,13 @@ inline void cpu_relax() {
 
 class ThreadPool {
  public:
-  explicit ThreadPool(int n_threads) {
+  // cpus != nullptr: the workers may only run on those cpus (the caller's thread is not touched)
+  explicit ThreadPool(int n_threads, const cpu_set_t* cpus = nullptr) {
     const int workers = n_threads > 1 ? n_threads - 1 : 0;
-    for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { worker(); });
+    for (int i = 0; i < workers; ++i) {
+      threads_.emplace_back([this] { worker(); });
+      if (cpus) (void)pthread_setaffinity_np(threads_.back().native_handle(), sizeof(cpu_set_t), cpus);
+    }
   }
   ~ThreadPool() {
     {
@@ -46,6 +54,30 @@ class ThreadPool {
   ThreadPool& operator=(const ThreadPool&) = delete;
 
   int size() const { return (int)threads_.size() + 1; }
+
+  // f() on one of the workers (on the calling thread when the pool has none); returns when done
+  template <typename F>
+  void run_on_worker(F&& f) {
+    if (threads_.empty()) { f(); return; }
+    Job job;
+    auto body = [&](int) { f(); };
+    job.call = [](void* ctx, int t) { (*static_cast<decltype(body)*>(ctx))(t); };
+    job.ctx = &body;
+    job.n = 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &job;
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    // the caller does NOT take part: wait for a worker to claim and finish the one task
+    while (job.done.load(std::memory_order_acquire) < 1) std::this_thread::yield();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = nullptr;
+    }
+    while (job.attached.load(std::memory_order_acquire) != 0) cpu_relax();
+  }
 
   // fn(task) for every task in [0, n_tasks); returns when all of them have finished.
   template <typename F>

@@ -171,6 +171,10 @@ int gp_predict_host(gp_ctx* ctx, const gp_model* model, int host_dtype, const vo
                     int64_t max_block_rows);
 /* number of host threads (caller included) the context uses for staging copies */
 int gp_ctx_host_threads(gp_ctx* ctx, int* n_threads);
+/* NUMA node the device is attached to (sysfs, by PCI bus id; -1 = unknown).  The context's helper
+ * threads and pinned staging live there (GP_HOST_PIN=0 disables); a caller that wants its own
+ * arrays there too binds itself to that node's cpus before allocating them. */
+int gp_device_numa_node(int device, int* node);
 
 /* ---- Hessian of the mean ------------------------------------------------------------------
  * Replaces GaussianProcess.hessian (gp_emulator/GaussianProcess.py:345-366; the reference

@@ -22,6 +22,8 @@ def best(fn, reps=5):
 
 
 def main():
+    if "--bind" in sys.argv:       # run next to the GPU, as bench.py does
+        print("bound to %d cpus next to device 0" % len(_lib.bind_near_device(0)))
     ctx = _lib.default_context(0)
     print("host threads = %d, GP_HOST_HUGEPAGES=%s, THP=%s" % (
         ctx.host_threads(), os.environ.get("GP_HOST_HUGEPAGES", "1"),
