@@ -879,3 +879,75 @@ def test_gpu_objective_reports_a_non_positive_definite_matrix(gpu_lib):
         gp.loglikelihood(theta, is_gpu=True)
     with pytest.raises(np.linalg.LinAlgError):
         gp.loglikelihood(theta, is_gpu=False)
+
+
+def test_multivariate_set_up_reports_a_non_positive_definite_component(gpu_lib):
+    """MultivariateEmulator(..., hyperparams given, is_gpu=True) takes every PC's inverse from one
+    batched launch; a component whose Q is not positive definite must raise LinAlgError (as the
+    host branch's Cholesky does, reference GaussianProcess.py:66) instead of silently installing
+    non-finite inverses."""
+    from gp_emulator_amd import MultivariateEmulator
+    rs = np.random.RandomState(5)
+    y = np.repeat(rs.random_sample((12, 2)), 2, axis=0)           # duplicate inputs: singular without noise
+    w = np.linspace(0, 1, 8)
+    X = np.outer(np.sin(3 * y[:, 0]), np.cos(2 * w)) + np.outer(y[:, 1] ** 2, w) + 0.01 * rs.standard_normal((24, 8))
+    good = np.tile(np.array([0.0, 0.0, 0.0, -6.0])[:, None], (1, 2))
+    MultivariateEmulator(X=X, y=y, hyperparams=good, n_pcs=2, is_gpu=True)            # fine with noise
+    bad = good.copy()
+    bad[3, 1] = -800.0                                            # second component: no noise at all
+    with pytest.raises(np.linalg.LinAlgError):
+        MultivariateEmulator(X=X, y=y, hyperparams=bad, n_pcs=2, is_gpu=True)
+
+
+# ---------------------------------------------------------------------------------------
+# the caches on the host path must never serve stale constants
+# ---------------------------------------------------------------------------------------
+def test_boundary_model_cache_follows_the_constants(gpu_lib):
+    """predict_wrap re-sends the emulator with every call; the library reuses a packed model only
+    when every constant compares equal byte for byte.  A / B / A / B-with-one-element-changed:
+    every answer must be the one of the constants passed in THAT call."""
+    a = synthetic_case("c1_n100_d5")
+    b = dict(a)
+    rs = np.random.RandomState(9)
+    b["invQ"], b["invQt"] = rs.random_sample(a["invQ"].shape), rs.random_sample(a["invQt"].shape)
+    c = dict(b)
+    c["invQ"] = b["invQ"].copy()
+    c["invQ"][7, 3] += 0.5                                        # one element differs
+    t = a["testing"][:300]
+    refs = [gp_oracle.cpu_predict(g["inputs"], g["theta"], g["invQ"], g["invQt"], t) for g in (a, b, c)]
+    for g, ref in ((a, refs[0]), (b, refs[1]), (a, refs[0]), (c, refs[2]), (b, refs[1]), (a, refs[0])):
+        assert max(errs(ref, wrap(g, np.float64, t))) <= 1e-10
+    # more emulators than cache slots, round robin
+    many = []
+    for k in range(6):
+        g = dict(a)
+        g["invQt"] = np.random.RandomState(20 + k).random_sample(a["invQt"].shape)
+        many.append((g, gp_oracle.cpu_predict(g["inputs"], g["theta"], g["invQ"], g["invQt"], t)))
+    for _ in range(2):
+        for g, ref in many:
+            assert max(errs(ref, wrap(g, np.float64, t))) <= 1e-10
+
+
+def test_gpu_model_follows_attribute_changes(gpu_lib):
+    """GaussianProcess keeps its packed model on the device between predict calls; theta / invQ /
+    invQt are plain attributes (as in the reference) and may be reassigned or modified IN PLACE --
+    the next predict must see the new values."""
+    g = synthetic_case("c1_n100_d5")
+    gp = make_gp(dict(g, invQ=g["invQ"].copy(), invQt=g["invQt"].copy(), theta=g["theta"].copy()))
+    t = g["testing"][:200]
+
+    def check():
+        ref = gp_oracle.cpu_predict(gp.inputs, gp.theta, gp.invQ, gp.invQt, t)
+        assert max(errs(ref, gp.predict(t, is_gpu=True))) <= 1e-10
+        assert gp_oracle.maxnorm_err(gp_oracle.hessian(gp.inputs, gp.theta, gp.invQt, t[:20]),
+                                     gp.hessian(t[:20], is_gpu=True)) <= 1e-10
+    check()
+    gp.invQt[5] += 1.0                        # in place
+    check()
+    gp.invQ[2, 9] -= 0.25                     # in place
+    check()
+    gp.theta = gp.theta + 0.1                 # reassigned
+    check()
+    m1 = gp.gpu_model(np.float64)
+    check()
+    assert gp.gpu_model(np.float64) is m1     # nothing changed: the same device model is reused

@@ -249,3 +249,28 @@ def test_learn_bands_lockstep_equals_threads_bit_for_bit():
     assert np.array_equal(out["lockstep"][0], out["threads"][0])
     assert np.array_equal(out["lockstep"][1], out["threads"][1])
     assert out["lockstep"][2]["evaluations"] == out["threads"][2]["evaluations"]
+
+
+def test_output_pool_reuses_only_unreferenced_buffers():
+    """_lib.OutputPool hands a buffer out again only when nothing but the pool refers to it: results
+    a caller still holds (or views of them) are never overwritten by a later predict."""
+    from gp_emulator_amd._lib import OutputPool
+    pool = OutputPool(max_item=64 << 20, max_total=40 << 20)
+    a = pool.take((2 << 20,), np.float64)                 # 16 MB
+    addr = a.ctypes.data
+    b = pool.take((2 << 20,), np.float64)
+    assert b.ctypes.data != addr                          # a is alive
+    del a
+    c = pool.take((1 << 20, 2), np.float64)               # same bytes, other shape
+    assert c.ctypes.data == addr and c.shape == (1 << 20, 2)
+    view = c[:10]
+    del c
+    d = pool.take((2 << 20,), np.float64)
+    assert d.ctypes.data != addr                          # a view of c is alive
+    view[:] = 7.0
+    assert np.all(view == 7.0)
+    assert sum(x.nbytes for x in pool.items) <= 40 << 20  # over budget: buffers are forgotten, not reused
+    small = pool.take((100,), np.float64)
+    assert small.base is None                             # small and oversize requests bypass the pool
+    big = pool.take((9 << 20,), np.float64)               # 72 MB > max_item
+    assert big.base is None
