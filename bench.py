@@ -343,20 +343,27 @@ def sample_parity(ctx, a, kind, bufs_out, inputs, testing, params, M, D, E, dtyp
     return worst, n_rows * len(set([0, E // 2, E - 1]))
 
 
-def e2e_leg(N, D, M, inputs, testing, theta, invQ, invQt, dtype):
+def e2e_leg(N, D, M, inputs, testing, theta, invQ, invQt, dtype, grp=None):
     """gp.predict(is_gpu=True) from host numpy arrays to host numpy arrays (default threshold),
-    the call tests/benchmark.py:41-44 times; median of 10 calls after 3 warm-up calls."""
+    the call tests/benchmark.py:41-44 times; median of 10 calls after 3 warm-up calls.  With more
+    than one rank every rank makes the same call on its own rows at the same moment (a barrier in
+    front of each call) and a call takes as long as its slowest rank: the aggregate is what the
+    host's DRAM and PCIe roots sustain with all the GPUs streaming at once."""
     from gp_emulator_amd import GaussianProcess
     gp = GaussianProcess(inputs, [])
     gp.theta, gp.invQ, gp.invQt = theta, invQ, invQt
+    world = 1 if grp is None else grp.world
     ts = []
     for k in range(13):
+        if world > 1:
+            grp.barrier()
         t0 = time.perf_counter()
         out = gp.predict(testing, is_gpu=True, precision=dtype)
-        ts.append(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
+        ts.append(grp.max(dt) if world > 1 else dt)
         del out
     first, steady = ts[0], float(np.median(ts[3:]))
-    return M / steady, steady, first
+    return world * M / steady, steady, first
 
 
 def bench_strong(a, grp):
@@ -465,6 +472,7 @@ def main():
     # one process per GPU: run on the cpus next to that GPU (numactl --cpunodebind by hand), so the
     # arrays generated below are first-touched on the socket the device's PCIe root belongs to
     near = _lib.bind_near_device(grp.local_rank % ndev)
+    _lib.set_default_device(grp.local_rank % ndev)      # gp.predict(is_gpu=True) in the e2e leg
     ctx = _lib.Context(grp.local_rank % ndev)
     info = ctx.device_info()
 
@@ -533,7 +541,7 @@ def main():
     if not max(errs.values()) <= tol and not a.no_parity:
         raise SystemExit("bench parity check failed: %s" % errs)
 
-    out = None
+    out, e2e = None, None
     if rank == 0:
         units = E * M                                  # (emulator, test point) pairs per step
         value = world * a.steps * units / dt
@@ -605,20 +613,25 @@ def main():
             "roofline": roof,
             "parity": dict(errs, tol=tol, checked_rows=int(n_checked)),
         }
-        if world == 1 and a.workload == "c2" and not a.no_e2e:
-            # host numpy in -> host numpy out through the same library (outside the timed region)
-            for p_ in bufs:
-                ctx.free(p_)
-            bufs = []
-            rate, steady, first = e2e_leg(N, D, M, inputs, testing, theta, invQ, invQt, dtype)
+    if a.workload == "c2" and not a.no_e2e:
+        # host numpy in -> host numpy out through the same library (outside the timed region); on
+        # every rank at once when there are several, so the line carries host-to-host scaling too
+        for p_ in bufs:
+            ctx.free(p_)
+        bufs = []
+        e2e = e2e_leg(N, D, M, inputs, testing, theta, invQ, invQt, dtype, grp)
+    if rank == 0:
+        if e2e is not None:
+            rate, steady, first = e2e
             roof["e2e_points_per_s"] = rate
             roof["e2e_ms_per_call"] = steady * 1e3
             roof["e2e_first_call_ms"] = first * 1e3
             out["end_to_end"] = {"value": rate, "unit": "test-points/s", "ms_per_call": steady * 1e3,
-                                 "first_call_ms": first * 1e3, "rows": M, "threshold": 2e5,
+                                 "first_call_ms": first * 1e3, "rows_per_gpu": M, "n_gpus": world, "threshold": 2e5,
                                  "what": "gp.predict(testing, is_gpu=True) from host numpy arrays to host numpy "
                                          "arrays, median of 10 calls after 3 warm-up calls (PCIe and host copies "
-                                         "included; tests/benchmark.py:41-44)"}
+                                         "included; tests/benchmark.py:41-44); with several ranks all of them "
+                                         "call at once and a call lasts as long as its slowest rank"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
             cpu["gpu_over_cpu"] = value / cpu["value"]          # resident GPU rate / reference-style CPU

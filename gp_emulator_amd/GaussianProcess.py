@@ -96,7 +96,7 @@ class GaussianProcess:
         theta = np.asarray(theta, dtype=np.float64)
         if is_gpu == True:  # noqa: E712
             from . import _lib
-            ctx = _lib.default_context(0)
+            ctx = _lib.default_context()
             cost, grad, invQ, invQt = ctx.likelihood_batch(theta[None, :], self.inputs,
                                                            self.targets, want_inverse=True)
             if not np.isfinite(cost[0]):
@@ -297,14 +297,15 @@ class GaussianProcess:
         return self.cpu_predict(testing, do_unc)
 
     # ------------------------------------------------------------------ device-resident use
-    def gpu_model(self, precision=np.float64, device=0):
+    def gpu_model(self, precision=np.float64, device=None):
         """Constants packed and uploaded once (cached per precision/device): what ``predict``
         and ``hessian`` run on, and the form to use when the test rows already live in HBM.
         The cache entry remembers the constants it was built from and is rebuilt when theta,
         inputs, invQt or invQ no longer compare equal (they are plain attributes, as in the
         reference, and callers assign them)."""
         from . import _lib
-        key = (np.dtype(precision).str, int(device))
+        device = _lib.default_device() if device is None else int(device)
+        key = (np.dtype(precision).str, device)
         invQ = getattr(self, "invQ", None)        # absent: a model for the Hessian alone
         consts = (np.asarray(self.theta), np.asarray(self.inputs), np.asarray(self.invQt),
                   np.asarray(invQ) if invQ is not None else np.empty(0))

@@ -9,6 +9,7 @@ from .GaussianProcess import GaussianProcess, k_fold_cross_validation  # noqa: F
 from .multivariate_gp import MultivariateEmulator  # noqa: F401
 from .lhd import lhd  # noqa: F401
 from .save_emulators import EmulatorStorage  # noqa: F401
+from ._lib import set_default_device  # noqa: F401  (ctypes only: loads nothing until first use)
 
 __all__ = ["GaussianProcess", "k_fold_cross_validation", "MultivariateEmulator", "lhd",
-           "EmulatorStorage"]
+           "EmulatorStorage", "set_default_device"]

@@ -77,7 +77,7 @@ def _call(kind, expX, inputs, invQt, invQ, testing, result, error, deriv,
     for name in ("result", "error", "deriv"):
         if not dict(zip(_NAMES, arrays))[name].flags["WRITEABLE"]:
             raise ValueError("%s must be writeable" % name)
-    ctx = _lib.default_context(0)
+    ctx = _lib.default_context()
     if kind == "rows_f32_h64":
         if dt != np.float64:
             raise TypeError("predict_rows_f32_h64 takes float64 arrays")

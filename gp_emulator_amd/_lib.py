@@ -495,9 +495,27 @@ def pack_model(expX, inputs, invQt, invQ, precision=np.float64):
 _tls = threading.local()
 
 
-def default_context(device=0):
+_default_device = [None]
+
+
+def set_default_device(device):
+    """The device the drop-in entry points (``predict(is_gpu=True)``, ``predict_wrap``, training with
+    ``is_gpu=True``) use in this process.  The reference always computes on device 0
+    (``gpu_predict.h``: no device selection at all); a one-process-per-GPU launch calls this once
+    with its local rank.  Initial value: ``$GP_DEVICE`` or 0."""
+    _default_device[0] = int(device)
+
+
+def default_device():
+    if _default_device[0] is None:
+        _default_device[0] = int(os.environ.get("GP_DEVICE", "0"))
+    return _default_device[0]
+
+
+def default_context(device=None):
     """Per-thread context per device for the drop-in entry points (a gp_ctx owns a stream
     and a scratch buffer, so it is not shared between threads)."""
+    device = default_device() if device is None else int(device)
     d = getattr(_tls, "ctx", None)
     if d is None:
         d = _tls.ctx = {}

@@ -95,7 +95,7 @@ class MultivariateEmulator(object):
         if is_gpu and self.n_pcs > 0:
             # the emulators differ in targets and theta only: one launch, one workgroup each
             from . import _lib
-            cost, grad, invQ, invQt = _lib.default_context(0).likelihood_batch(
+            cost, grad, invQ, invQt = _lib.default_context().likelihood_batch(
                 self.hyperparams.T, np.atleast_2d(y), train_data, want_inverse=True)
             bad = np.flatnonzero(~np.isfinite(cost))
             if bad.size:

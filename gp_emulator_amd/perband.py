@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 
 
-def make_batch(gps, precision=np.float64, device=0):
+def make_batch(gps, precision=np.float64, device=None):
     """Pack a list of GaussianProcess objects sharing ``inputs`` into one BatchModel."""
     if not gps:
         raise ValueError("need at least one GaussianProcess")
@@ -26,7 +26,7 @@ def make_batch(gps, precision=np.float64, device=0):
     return _lib.BatchModel(_lib.default_context(device), expX, inputs, invQt, invQ, precision)
 
 
-def predict_bands(gps, testing, precision=np.float64, device=0):
+def predict_bands(gps, testing, precision=np.float64, device=None):
     """mu (E, M), var (E, M), deriv (E, M, D) for the E emulators in ``gps``."""
     batch = make_batch(gps, precision, device)
     try:
@@ -243,7 +243,7 @@ def _finite(cost_grad):
 
 
 def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch_fn=None,
-                device=0, verbose=False, method="auto"):
+                device=None, verbose=False, method="auto"):
     """``learn_hyperparameters(n_tries)`` for every GaussianProcess in ``gps`` (per-band
     emulators on the SAME training inputs, tests/test_perband_emulator.py:22-37), with the
     optimisations of all bands and all restarts advancing side by side: ``concurrency``

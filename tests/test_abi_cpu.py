@@ -44,6 +44,20 @@ def test_no_gpu_fails_loudly_not_silently():
         gp.gpu_model()
 
 
+def test_default_device_is_a_process_setting(monkeypatch):
+    """The reference computes on device 0 and has no way to choose; one process per GPU sets
+    the device once (or exports GP_DEVICE) and every drop-in entry point follows."""
+    import gp_emulator_amd
+    monkeypatch.setattr(_lib, "_default_device", [None])
+    monkeypatch.setenv("GP_DEVICE", "5")
+    assert _lib.default_device() == 5
+    gp_emulator_amd.set_default_device(2)
+    assert _lib.default_device() == 2
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.GpuPredictUnavailable):
+            _lib.default_context()
+
+
 def mfma_rows(dtype):
     """own_sub(r, g): row inside a 16-block of C/D register r for lane group g."""
     if np.dtype(dtype) == np.float64:
