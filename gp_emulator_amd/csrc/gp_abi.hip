@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -60,6 +61,21 @@ static int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// No C++ exception may cross the C boundary: the exported functions that allocate host memory
+// (packing buffers, cache keys) run their bodies through this.
+template <typename F>
+static int guarded(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail(GP_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception& ex) {
+    return fail(GP_ERR_INVALID, "%s", ex.what());
+  } catch (...) {
+    return fail(GP_ERR_INVALID, "unknown C++ exception");
+  }
 }
 
 #define HIP_TRY(expr)                                                                 \
@@ -323,7 +339,7 @@ int gp_ctx_create(int device, gp_ctx** out) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   gp_ctx* c = new (std::nothrow) gp_ctx();
-  if (!c) return fail(GP_ERR_INVALID, "out of host memory");
+  if (!c) return fail(GP_ERR_NOMEM, "out of host memory");
   c->device = device;
   c->compute_units = prop.multiProcessorCount;
   c->scratch = nullptr;
@@ -408,12 +424,12 @@ int gp_pack_sizes(int dtype, int n_train, int n_inputs, int* kernel_d, int* kern
 int gp_pack_model_f64(const double* expX, const double* inputs, const double* invQt,
                       const double* invQ, int n_train, int n_inputs, int theta_size,
                       double* xa, double* frags, double* sd, double* b) {
-  return pack_model<double>(expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, xa, frags, sd, b);
+  return guarded([&] { return pack_model<double>(expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, xa, frags, sd, b); });
 }
 int gp_pack_model_f32(const float* expX, const float* inputs, const float* invQt,
                       const float* invQ, int n_train, int n_inputs, int theta_size,
                       float* xa, float* frags, float* sd, float* b) {
-  return pack_model<float>(expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, xa, frags, sd, b);
+  return guarded([&] { return pack_model<float>(expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, xa, frags, sd, b); });
 }
 
 }  // extern "C"
@@ -435,7 +451,7 @@ static int model_create(gp_ctx* ctx, int E, const TH* expX, const TH* inputs, co
   if (!invQ) fr_len = 0;
   HIP_TRY(hipSetDevice(ctx->device));
   gp_model* m = new (std::nothrow) gp_model();
-  if (!m) return fail(GP_ERR_INVALID, "out of host memory");
+  if (!m) return fail(GP_ERR_NOMEM, "out of host memory");
   m->device = ctx->device;
   m->dtype = sizeof(T) == 8 ? GP_F64 : GP_F32;
   m->n_train = N;
@@ -1112,26 +1128,26 @@ extern "C" {
 
 int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                         const double* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
-  return model_create<double>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return guarded([&] { return model_create<double>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out); });
 }
 int gp_batch_create_f64(gp_ctx* ctx, int n_emulators, const double* expX, const double* inputs,
                         const double* invQt, const double* invQ, int n_train, int n_inputs,
                         int theta_size, gp_model** out) {
-  return model_create<double>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return guarded([&] { return model_create<double>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out); });
 }
 int gp_batch_create_f32(gp_ctx* ctx, int n_emulators, const float* expX, const float* inputs,
                         const float* invQt, const float* invQ, int n_train, int n_inputs,
                         int theta_size, gp_model** out) {
-  return model_create<float>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return guarded([&] { return model_create<float>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out); });
 }
 int gp_model_create_f32_h64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                             const double* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
-  return model_create<float, double>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return guarded([&] { return model_create<float, double>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out); });
 }
 int gp_batch_create_f32_h64(gp_ctx* ctx, int n_emulators, const double* expX, const double* inputs,
                             const double* invQt, const double* invQ, int n_train, int n_inputs,
                             int theta_size, gp_model** out) {
-  return model_create<float, double>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return guarded([&] { return model_create<float, double>(ctx, n_emulators, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out); });
 }
 int gp_model_emulators(const gp_model* m, int* n_emulators) {
   if (!m || !n_emulators) return fail(GP_ERR_INVALID, "null pointer");
@@ -1140,7 +1156,7 @@ int gp_model_emulators(const gp_model* m, int* n_emulators) {
 }
 int gp_model_create_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
                         const float* invQ, int n_train, int n_inputs, int theta_size, gp_model** out) {
-  return model_create<float>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out);
+  return guarded([&] { return model_create<float>(ctx, 1, expX, inputs, invQt, invQ, n_train, n_inputs, theta_size, out); });
 }
 
 int gp_model_destroy(gp_model* m) {
@@ -1201,14 +1217,14 @@ int gp_predict_host(gp_ctx* ctx, const gp_model* model, int host_dtype, const vo
   if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
   if (!model->d_frags) return fail(GP_ERR_INVALID, "model was created without invQ: no variance operand");
   if (model->dtype == GP_F64 && host_dtype == GP_F64)
-    return predict_host<double, double>(ctx, model, (const double*)testing, (double*)result, (double*)error,
-                                        (double*)deriv, n_predict, deriv_layout, max_block_rows);
+    return guarded([&] { return predict_host<double, double>(ctx, model, (const double*)testing, (double*)result, (double*)error,
+                                        (double*)deriv, n_predict, deriv_layout, max_block_rows); });
   if (model->dtype == GP_F32 && host_dtype == GP_F32)
-    return predict_host<float, float>(ctx, model, (const float*)testing, (float*)result, (float*)error,
-                                      (float*)deriv, n_predict, deriv_layout, max_block_rows);
+    return guarded([&] { return predict_host<float, float>(ctx, model, (const float*)testing, (float*)result, (float*)error,
+                                      (float*)deriv, n_predict, deriv_layout, max_block_rows); });
   if (model->dtype == GP_F32 && host_dtype == GP_F64)
-    return predict_host<float, double>(ctx, model, (const double*)testing, (double*)result, (double*)error,
-                                       (double*)deriv, n_predict, deriv_layout, max_block_rows);
+    return guarded([&] { return predict_host<float, double>(ctx, model, (const double*)testing, (double*)result, (double*)error,
+                                       (double*)deriv, n_predict, deriv_layout, max_block_rows); });
   return fail(GP_ERR_INVALID, "host arrays must have the model's dtype, or be float64 for a float32 model");
 }
 
@@ -1221,8 +1237,8 @@ int gp_hessian_host(gp_ctx* ctx, const gp_model* model, const void* testing, voi
   if (model->n_emulators != 1) return fail(GP_ERR_INVALID, "hessian is per emulator: batch of %d given", model->n_emulators);
   if (model->n_inputs > GP_MAX_KERNEL_D)
     return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
-  if (model->dtype == GP_F64) return hessian_host_model<double>(ctx, model, (const double*)testing, (double*)hess, n_predict);
-  return hessian_host_model<float>(ctx, model, (const float*)testing, (float*)hess, n_predict);
+  if (model->dtype == GP_F64) return guarded([&] { return hessian_host_model<double>(ctx, model, (const double*)testing, (double*)hess, n_predict); });
+  return guarded([&] { return hessian_host_model<float>(ctx, model, (const float*)testing, (float*)hess, n_predict); });
 }
 
 int gp_device_numa_node(int device, int* node) {
@@ -1240,14 +1256,14 @@ int gp_ctx_host_threads(gp_ctx* ctx, int* n_threads) {
 int gp_predict_wrap_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                         const double* invQ, const double* testing, double* result, double* error,
                         double* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
-  return predict_wrap<double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
-                              n_predict, n_train, n_inputs, theta_size);
+  return guarded([&] { return predict_wrap<double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                              n_predict, n_train, n_inputs, theta_size); });
 }
 int gp_predict_wrap_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
                         const float* invQ, const float* testing, float* result, float* error,
                         float* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
-  return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
-                             n_predict, n_train, n_inputs, theta_size);
+  return guarded([&] { return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                             n_predict, n_train, n_inputs, theta_size); });
 }
 
 int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing, void* d_hess,
@@ -1259,37 +1275,37 @@ int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
   if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
   if (model->n_emulators != 1) return fail(GP_ERR_INVALID, "hessian is per emulator: batch of %d given", model->n_emulators);
   HIP_TRY(hipSetDevice(ctx->device));
-  if (model->dtype == GP_F64) return hessian_device<double>(ctx, model, d_testing, d_hess, n_predict);
-  return hessian_device<float>(ctx, model, d_testing, d_hess, n_predict);
+  if (model->dtype == GP_F64) return guarded([&] { return hessian_device<double>(ctx, model, d_testing, d_hess, n_predict); });
+  return guarded([&] { return hessian_device<float>(ctx, model, d_testing, d_hess, n_predict); });
 }
 int gp_hessian_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                    const double* testing, double* hess, int64_t n_predict, int n_train,
                    int n_inputs, int theta_size) {
-  return hessian_host<double>(ctx, expX, inputs, invQt, testing, hess, n_predict, n_train, n_inputs, theta_size);
+  return guarded([&] { return hessian_host<double>(ctx, expX, inputs, invQt, testing, hess, n_predict, n_train, n_inputs, theta_size); });
 }
 int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
                    const float* testing, float* hess, int64_t n_predict, int n_train,
                    int n_inputs, int theta_size) {
-  return hessian_host<float>(ctx, expX, inputs, invQt, testing, hess, n_predict, n_train, n_inputs, theta_size);
+  return guarded([&] { return hessian_host<float>(ctx, expX, inputs, invQt, testing, hess, n_predict, n_train, n_inputs, theta_size); });
 }
 
 int gp_predict_rows_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                         const double* invQ, const double* testing, double* result, double* error,
                         double* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
-  return predict_wrap<double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
-                              n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
+  return guarded([&] { return predict_wrap<double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                              n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR); });
 }
 int gp_predict_rows_f32_h64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                             const double* invQ, const double* testing, double* result, double* error,
                             double* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
-  return predict_wrap<float, double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
-                                     n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
+  return guarded([&] { return predict_wrap<float, double>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                                     n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR); });
 }
 int gp_predict_rows_f32(gp_ctx* ctx, const float* expX, const float* inputs, const float* invQt,
                         const float* invQ, const float* testing, float* result, float* error,
                         float* deriv, int64_t n_predict, int n_train, int n_inputs, int theta_size) {
-  return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
-                             n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR);
+  return guarded([&] { return predict_wrap<float>(ctx, expX, inputs, invQt, invQ, testing, result, error, deriv,
+                             n_predict, n_train, n_inputs, theta_size, GP_DERIV_ROWMAJOR); });
 }
 
 int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const void* d_coef,
@@ -1400,7 +1416,7 @@ int gp_event_create(gp_ctx* ctx, gp_event** out) {
   if (!ctx || !out) return fail(GP_ERR_INVALID, "null pointer");
   HIP_TRY(hipSetDevice(ctx->device));
   gp_event* e = new (std::nothrow) gp_event();
-  if (!e) return fail(GP_ERR_INVALID, "out of host memory");
+  if (!e) return fail(GP_ERR_NOMEM, "out of host memory");
   e->device = ctx->device;
   hipError_t r = hipEventCreate(&e->ev);
   if (r != hipSuccess) {

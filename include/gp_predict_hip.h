@@ -36,7 +36,8 @@ typedef enum gp_status {
   GP_ERR_INVALID = -1,      /* bad argument (null pointer, size <= 0, unsupported shape) */
   GP_ERR_HIP = -2,          /* a HIP runtime call failed (see gp_last_error_string) */
   GP_ERR_NO_DEVICE = -3,    /* no usable GPU */
-  GP_ERR_UNSUPPORTED = -4   /* shape outside the compiled kernel set */
+  GP_ERR_UNSUPPORTED = -4,  /* shape outside the compiled kernel set */
+  GP_ERR_NOMEM = -5         /* a host allocation failed (no C++ exception ever crosses this boundary) */
 } gp_status;
 
 typedef enum gp_dtype { GP_F32 = 0, GP_F64 = 1 } gp_dtype;
