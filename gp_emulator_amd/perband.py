@@ -159,57 +159,227 @@ class _Instance(object):
         self.failed = False
 
 
-def _learn_lockstep(setulb, batch_fn, targets, starts, max_batch=4096):
-    """Every (emulator, restart) optimisation advances through scipy's own L-BFGS-B routine, one
-    thread, no callbacks: each instance is stepped until it asks for a cost/gradient, then ALL the
-    requests are evaluated in one batched call.  Iterates are those of ``fmin_l_bfgs_b(factr=0.1,
-    pgtol=1e-20)`` (reference GaussianProcess.py:168-170) because it is the same routine fed the
-    same numbers."""
-    E, n_tries, n = starts.shape
+class _Population(object):
+    """A set of L-BFGS-B instances advanced in lockstep: ``advance(results)`` hands the instances
+    that asked last time their costs and gradients, steps every live instance through scipy's
+    routine until it asks for a cost/gradient or stops, and returns the new requests and the
+    instances that finished.  Lives in the calling process or in a worker process (``_worker``)."""
+
     factr, pgtol, m, maxls, maxfun, maxiter = 0.1, 1e-20, 10, 20, 15000, 15000
-    live = [_Instance(e, k, starts[e, k]) for e in range(E) for k in range(n_tries)]
-    cost = np.full((E, n_tries), np.inf)
-    theta = np.zeros((E, n_tries, n))
-    launches = evaluations = 0
-    while live:
-        asking, still = [], []
-        for it in live:
-            while True:
-                setulb(m, it.x, it.low, it.up, it.nbd, it.f, it.g, factr, pgtol, it.wa, it.iwa,
-                       it.task, it.lsave, it.isave, it.dsave, maxls, it.ln_task)
-                if it.task[0] == 3:                      # wants f and g at x
-                    if it.nfev and np.array_equal(it.x, it.last_good):
-                        continue                         # same point again: f, g are current
-                    asking.append(it)                    # (what scipy's ScalarFunction cache does)
-                    break
-                if it.task[0] == 1:                      # new iteration
-                    it.nit += 1
-                    if it.nit >= maxiter:
-                        it.task[0], it.task[1] = 5, 504
-                    elif it.nfev > maxfun:
-                        it.task[0], it.task[1] = 5, 502
-                    continue
-                cost[it.e, it.k], theta[it.e, it.k] = it.f, it.x   # converged / stopped
-                break
-        for s0 in range(0, len(asking), max_batch):
-            part = asking[s0:s0 + max_batch]
-            th = np.stack([it.x for it in part])
-            tg = targets[[it.e for it in part]]
-            c, g = batch_fn(th, tg)
-            launches += 1
-            evaluations += len(part)
-            for j, it in enumerate(part):
+
+    def __init__(self, setulb, ids, starts):
+        self.setulb = setulb
+        self.n = int(np.asarray(starts).shape[1])
+        self.live = [_Instance(e, k, x0) for (e, k), x0 in zip(ids, starts)]
+        self.asking = []
+
+    def advance(self, results):
+        """results: (cost (A,), grad (A, n)) for the A requests returned by the previous call
+        (None the first time).  Returns (thetas (A', n), e (A',), finished) where finished is a
+        list of (e, k, cost, theta)."""
+        finished = []
+        if results is not None:
+            c, g = results
+            keep = []
+            for j, it in enumerate(self.asking):
                 it.nfev += 1
                 if not np.isfinite(c[j]):
                     # a pivot <= 0: the reference's numpy path raises LinAlgError here and its
                     # optimiser loop gives the restart up with cost 9999 (:176-181)
-                    cost[it.e, it.k], theta[it.e, it.k] = 9999.0, it.last_good
-                    it.failed = True
+                    finished.append((it.e, it.k, 9999.0, it.last_good))
                 else:
                     it.f = float(c[j])
-                    it.g = np.ascontiguousarray(g[j], dtype=np.float64)
-                    it.last_good = it.x.copy()
-        live = [it for it in asking if not it.failed]
+                    it.g[:] = g[j]
+                    it.last_good[:] = it.x
+                    keep.append(it)
+            self.live = keep
+        setulb, m, factr, pgtol, maxls = self.setulb, self.m, self.factr, self.pgtol, self.maxls
+        asking = []
+        for it in self.live:
+            while True:
+                setulb(m, it.x, it.low, it.up, it.nbd, it.f, it.g, factr, pgtol, it.wa, it.iwa,
+                       it.task, it.lsave, it.isave, it.dsave, maxls, it.ln_task)
+                task = it.task[0]
+                if task == 3:                            # wants f and g at x
+                    if it.nfev and it.x.tobytes() == it.last_good.tobytes():
+                        continue                         # same point again: f, g are current
+                    asking.append(it)                    # (what scipy's ScalarFunction cache does)
+                    break
+                if task == 1:                            # new iteration
+                    it.nit += 1
+                    if it.nit >= self.maxiter:
+                        it.task[0], it.task[1] = 5, 504
+                    elif it.nfev > self.maxfun:
+                        it.task[0], it.task[1] = 5, 502
+                    continue
+                finished.append((it.e, it.k, it.f, it.x.copy()))   # converged / stopped
+                break
+        self.asking = self.live = asking
+        th = np.stack([it.x for it in asking]) if asking else np.zeros((0, self.n))
+        es = np.array([it.e for it in asking], dtype=np.int64)
+        return th, es, finished
+
+
+def _worker_main():
+    """Body of a lockstep worker process (``python -c "from gp_emulator_amd.perband import
+    _worker_main; _worker_main()"``): a _Population driven over its stdin / stdout with pickled
+    messages.  It never touches the GPU -- the objective is evaluated by the parent, for all
+    workers' requests at once.  A plain child process rather than ``multiprocessing``: a spawned
+    multiprocessing child re-imports the caller's main script, which a library must not require
+    to be import-safe."""
+    import os
+    import pickle
+    import sys
+    inp, out = sys.stdin.buffer, os.fdopen(os.dup(sys.stdout.fileno()), "wb")
+    sys.stdout = sys.stderr                       # nothing but messages on the pipe
+    try:
+        ids, starts = pickle.load(inp)
+        pop = _Population(_lockstep_driver(), ids, starts)
+        results = None
+        while True:
+            pickle.dump(pop.advance(results), out, protocol=4)
+            out.flush()
+            results = pickle.load(inp)
+            if results is None:
+                return
+    except EOFError:
+        return
+    except BaseException as exc:                  # report, the parent raises
+        try:
+            pickle.dump(RuntimeError("%s: %s" % (type(exc).__name__, exc)), out, protocol=4)
+            out.flush()
+        except Exception:
+            pass
+
+
+def _lockstep_processes(n_instances, processes):
+    """How many worker processes step the optimisers.  scipy's routine holds the GIL and costs
+    ~10 us of host time per evaluation -- 2e6 evaluations for 2101 bands x 5 restarts -- while the
+    GPU needs 1.5 us for the same evaluation, so large jobs spread the stepping over processes;
+    small ones are not worth the workers' start-up (an interpreter + numpy + scipy each)."""
+    if processes is not None:
+        return max(0, int(processes))
+    if n_instances < 2048:
+        return 0
+    import os
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(0, min(8, avail - 1, n_instances // 512))
+
+
+def _learn_lockstep(setulb, batch_fn, targets, starts, max_batch=4096, processes=0):
+    """Every (emulator, restart) optimisation advances through scipy's own L-BFGS-B routine, no
+    callbacks: each instance is stepped until it asks for a cost/gradient, then ALL the requests
+    are evaluated in one batched call.  Iterates are those of ``fmin_l_bfgs_b(factr=0.1,
+    pgtol=1e-20)`` (reference GaussianProcess.py:168-170) because it is the same routine fed the
+    same numbers.  ``processes`` > 0: the instances are dealt to that many worker processes
+    (child interpreters that import numpy and scipy and never touch the GPU); the parent only
+    gathers their requests, runs the batched objective and scatters the answers."""
+    E, n_tries, n = starts.shape
+    ids = [(e, k) for e in range(E) for k in range(n_tries)]
+    flat = starts.reshape(E * n_tries, n)
+    cost = np.full((E, n_tries), np.inf)
+    theta = np.zeros((E, n_tries, n))
+    launches = evaluations = 0
+
+    def evaluate(th, es):
+        nonlocal launches, evaluations
+        c = np.empty(len(th))
+        g = np.empty((len(th), n))
+        for s0 in range(0, len(th), max_batch):
+            c[s0:s0 + max_batch], g[s0:s0 + max_batch] = batch_fn(th[s0:s0 + max_batch], targets[es[s0:s0 + max_batch]])
+            launches += 1
+        evaluations += len(th)
+        return c, g
+
+    def record(finished):
+        for e, k, f, x in finished:
+            cost[e, k], theta[e, k] = f, x
+
+    if processes <= 0:
+        pop = _Population(setulb, ids, flat)
+        results = None
+        while True:
+            th, es, finished = pop.advance(results)
+            record(finished)
+            if not len(th):
+                break
+            results = evaluate(th, es)
+        return cost, theta, launches, evaluations
+
+    import os
+    import pickle
+    import subprocess
+    import sys
+    # the workers' BLAS must be single-threaded: the routine makes tiny LAPACK calls, and several
+    # processes each spinning a thread team per call are hundreds of times slower than one thread
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "BLIS_NUM_THREADS"):
+        env[k] = "1"
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    code = "from gp_emulator_amd.perband import _worker_main; _worker_main()"
+    workers = []
+
+    def send(proc, msg):
+        pickle.dump(msg, proc.stdin, protocol=4)
+        proc.stdin.flush()
+
+    try:
+        for w in range(processes):
+            mine = list(range(w, len(ids), processes))          # dealt round-robin: even load
+            proc = subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE,
+                                    stdout=subprocess.PIPE, env=env)
+            workers.append(proc)
+            send(proc, ([ids[i] for i in mine], flat[mine]))
+        # two groups of workers take turns: while the objective of one group's requests runs on
+        # the GPU (the GIL is released in the call), the other group's optimisers are stepping
+        groups = [list(range(0, processes, 2)), list(range(1, processes, 2))]
+        while groups[0] or groups[1]:
+            for gi in (0, 1):
+                if not groups[gi]:
+                    continue
+                asked = []
+                for w in groups[gi]:
+                    try:
+                        msg = pickle.load(workers[w].stdout)
+                    except EOFError:
+                        raise RuntimeError("lockstep worker %d exited (status %s)" % (w, workers[w].poll()))
+                    if isinstance(msg, BaseException):
+                        raise RuntimeError("lockstep worker %d failed: %s" % (w, msg))
+                    th, es, finished = msg
+                    record(finished)
+                    asked.append((w, th, es))
+                th_all = np.concatenate([th for _, th, _ in asked])
+                es_all = np.concatenate([es for _, _, es in asked])
+                c, g = evaluate(th_all, es_all) if len(th_all) else (np.zeros(0), np.zeros((0, n)))
+                s0, still = 0, []
+                for w, th, _ in asked:
+                    k = len(th)
+                    if k:
+                        send(workers[w], (c[s0:s0 + k], g[s0:s0 + k]))
+                        still.append(w)
+                    else:
+                        send(workers[w], None)              # nothing left in that worker
+                    s0 += k
+                groups[gi] = still
+        for proc in workers:
+            proc.wait(10)
+    finally:
+        for proc in workers:                            # the exact children started above
+            for fh in (proc.stdin, proc.stdout):
+                try:
+                    fh.close()
+                except Exception:
+                    pass
+            if proc.poll() is None:
+                proc.terminate()
+                try:
+                    proc.wait(5)
+                except Exception:
+                    proc.kill()
     return cost, theta, launches, evaluations
 
 
@@ -243,7 +413,7 @@ def _finite(cost_grad):
 
 
 def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch_fn=None,
-                device=None, verbose=False, method="auto"):
+                device=None, verbose=False, method="auto", processes=None):
     """``learn_hyperparameters(n_tries)`` for every GaussianProcess in ``gps`` (per-band
     emulators on the SAME training inputs, tests/test_perband_emulator.py:22-37), with the
     optimisations of all bands and all restarts advancing side by side: ``concurrency``
@@ -295,12 +465,15 @@ def learn_bands(gps, n_tries=5, concurrency=256, is_gpu=True, starts=None, batch
         raise ValueError("method must be 'auto', 'lockstep' or 'threads'")
     if setulb is not None:
         tg_all = np.stack([np.asarray(gp.targets, dtype=np.float64) for gp in gps])
-        best_cost, best_theta, launches, evaluations = _learn_lockstep(setulb, batch_fn, tg_all, starts)
+        n_proc = _lockstep_processes(E * n_tries, processes)
+        best_cost, best_theta, launches, evaluations = _learn_lockstep(setulb, batch_fn, tg_all, starts,
+                                                                       processes=n_proc)
         pick = np.argmin(best_cost, axis=1)
         costs = best_cost[np.arange(E), pick]
         thetas = best_theta[np.arange(E), pick]
         _leave_set(gps, thetas, inputs, ctx)
-        stats = {"launches": launches, "evaluations": evaluations, "threads": 1, "method": "lockstep"}
+        stats = {"launches": launches, "evaluations": evaluations, "threads": 1, "method": "lockstep",
+                 "processes": n_proc}
         if verbose:
             print("learn_bands: %d emulators x %d starts, %d evaluations in %d launches" % (
                 E, n_tries, evaluations, launches))

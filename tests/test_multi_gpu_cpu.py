@@ -251,6 +251,34 @@ def test_learn_bands_lockstep_equals_threads_bit_for_bit():
     assert out["lockstep"][2]["evaluations"] == out["threads"][2]["evaluations"]
 
 
+def test_learn_bands_worker_processes_change_nothing_but_the_wall_clock():
+    """processes > 0 deals the optimisers to child interpreters (scipy's routine holds the GIL);
+    the parent gathers their requests into the same batched objective.  Same iterates, same
+    evaluation count, same optimum -- and a failing objective still surfaces in the caller."""
+    from gp_emulator_amd import GaussianProcess, perband
+    if perband._lockstep_driver() is None:
+        pytest.skip("this scipy does not expose the reverse-communication routine")
+    assert perband._lockstep_processes(100, None) == 0 and perband._lockstep_processes(100, 3) == 3
+    X, bands = _bands_problem(n_bands=4)
+    out = {}
+    for procs in (0, 3):
+        gps = [GaussianProcess(X, t) for t in bands]
+        np.random.seed(5)
+        calls = []
+        out[procs] = perband.learn_bands(gps, n_tries=2, method="lockstep", processes=procs,
+                                         batch_fn=_numpy_objective(X, calls))
+        # one batch per round, or one per group of workers (two groups take turns): 8 = 5 + 3
+        assert out[procs][2]["processes"] == procs and max(calls) == (8 if procs == 0 else 5)
+    assert np.array_equal(out[0][0], out[3][0]) and np.array_equal(out[0][1], out[3][1])
+    assert out[0][2]["evaluations"] == out[3][2]["evaluations"]
+
+    def broken(thetas, targets):
+        raise RuntimeError("objective failed")
+    with pytest.raises(RuntimeError):
+        perband.learn_bands([GaussianProcess(X, t) for t in bands], n_tries=2, method="lockstep",
+                            processes=2, batch_fn=broken)
+
+
 def test_output_pool_reuses_only_unreferenced_buffers():
     """_lib.OutputPool hands a buffer out again only when nothing but the pool refers to it: results
     a caller still holds (or views of them) are never overwritten by a later predict."""

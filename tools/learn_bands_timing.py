@@ -24,6 +24,7 @@ ap.add_argument("--tries", type=int, default=5)
 ap.add_argument("--concurrency", type=int, default=256)
 ap.add_argument("--single", type=int, default=4)
 ap.add_argument("--method", default="auto")
+ap.add_argument("--processes", type=int, default=None, help="lockstep worker processes (default: learn_bands decides)")
 a = ap.parse_args()
 with np.load(os.path.join(ROOT, "tests", "golden", "prosail_mv.npz"), allow_pickle=False) as f:
     X_train, y_train = f["train_data"].T @ f["basis_functions"], f["y_train"]
@@ -34,12 +35,13 @@ gps = [GaussianProcess(y_train * 1, t) for t in targets]
 warnings.simplefilter("ignore")
 np.random.seed(5)
 t0 = time.time()
-costs, thetas, stats = perband.learn_bands(gps, n_tries=a.tries, concurrency=a.concurrency, method=a.method)
+costs, thetas, stats = perband.learn_bands(gps, n_tries=a.tries, concurrency=a.concurrency, method=a.method,
+                                           processes=a.processes)
 dt = time.time() - t0
 print("learn_bands[%s]: %d bands x %d starts in %.2f s (%.4f s per band); %d evaluations in %d launches "
-      "(%.1f per launch), %d optimiser threads" % (stats["method"], a.bands, a.tries, dt, dt / a.bands,
-                                                    stats["evaluations"], stats["launches"],
-                                                    stats["evaluations"] / stats["launches"], stats["threads"]))
+      "(%.1f per launch), %d optimiser threads, %s worker processes" % (
+          stats["method"], a.bands, a.tries, dt, dt / a.bands, stats["evaluations"], stats["launches"],
+          stats["evaluations"] / stats["launches"], stats["threads"], stats.get("processes", 0)))
 np.random.seed(5)
 t0 = time.time()
 worst = 0.0
