@@ -18,8 +18,10 @@
 //     the 8 x 8 pivot block along in its first lanes and reads every step's pivot row out of it
 //     with v_readlane), and applies all 8 rank-1 updates to every tile with two
 //     v_mfma_f64_16x16x4_f64:  tile += C^T W,  C[k][i] = -s_i p_k w^(k)_i,  W[k][j] = w^(k)_j,
-//     both operands read from the LDS panels; finally the finished pivot rows / columns replace
-//     the corresponding registers;
+//     both operands read from the LDS panels (all 38 reads of a wave first, then its 34 matrix
+//     instructions back to back, no branch between the tiles); finally the finished pivot rows /
+//     columns (a third panel, s_F) replace the corresponding registers.  Two barriers per pass:
+//     the next pass stages its pivot rows into s_R, which the update phase never reads;
 //   * Q itself is built straight into the tiles, the finished inverse is written to global
 //     memory once (both triangles) for invQt and the caller, and the gradient sums
 //     (likelihood_grad_kernel's work) follow in the same kernel from that L2-hot copy: one kernel
@@ -67,9 +69,10 @@ constexpr int tmB = 8;             // pivots per pass (== tkB)
 template <int DM>
 __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs p) {
   typedef f64x4 acc_t;
-  __shared__ double s_R[tmB * tmLd];      // the panel: pivot rows, finished in place
+  __shared__ double s_R[tmB * tmLd];      // the panel: the pivot rows as staged
   __shared__ double s_W[tmB * tmLd];      // w^(k): pivot row k / pivot at its own step
   __shared__ double s_C[tmB * tmLd];      // -s_i p_k w^(k)_i: the A operand of the update
+  __shared__ double s_F[tmB * tmLd];      // the finished pivot rows
   __shared__ double s_vec[tmNP];          // targets
   __shared__ double s_a[tmNP];            // invQt
   __shared__ double s_piv[tmNP];          // the pivots (their logs sum to logdet Q)
@@ -157,13 +160,6 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
     const unsigned rowmask = own < 0 ? 0u : ((2u << thi) - 1u) & ~((1u << tlo) - 1u);
     const unsigned belowmask = (t1 >= 0 ? 1u << t1 : 0u) | (t2 >= 0 ? 1u << t2 : 0u);
     const unsigned colmask = belowmask | (own < 0 ? 0u : 1u << thi);     // + the diagonal tile
-    const unsigned livemask = [&] {             // tiles not wholly in the padding
-      const int nbl = (N + 15) >> 4;            // live block rows / columns
-      const unsigned a = wv < nbl ? (1u << (wv + 1 < nbl ? wv + 1 : nbl)) - 1u : 0u;                 // row wv: C < nbl
-      const int cb = tmNB - wv;                 // tiles of row 15 - wv
-      const unsigned bmsk = tmNB - 1 - wv < nbl ? ((1u << (cb < nbl ? cb : nbl)) - 1u) << (wv + 1) : 0u;
-      return a | bmsk;
-    }();
     const int lrow = g * tmLd + ml;              // this lane's offset inside a panel row pair
     // (1) the 8 pivot rows -> s_R.  Columns up to the pivot block come from the tiles of block row
     // Ib (registers 2 h and 2 h + 1 hold rows 8 h + g and 8 h + 4 + g); columns right of it from
@@ -235,27 +231,43 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
       // finished pivot rows: panel columns from their threads, the pivot block from wave 0
 #pragma unroll
       for (int r = 0; r < tmB; ++r) {
-        if (!inK) s_R[r * tmLd + j] = col[r];
-        if (tid < tmB) s_R[r * tmLd + k0 + tid] = blk[r];
+        if (!inK) s_F[r * tmLd + j] = col[r];
+        if (tid < tmB) s_F[r * tmLd + k0 + tid] = blk[r];
       }
     }
     __syncthreads();
     TM_STAMP(3);
-    // (4) all 8 rank-1 updates on every tile, then the finished pivot rows and columns
+    // (4) the update of every tile, then the finished pivot rows and columns.  All operand reads
+    // first (one LDS latency for the lot), then the matrix instructions back to back.
+    {
+      const int Rw = wv, Rv = tmNB - 1 - wv;
+      const double aw0 = s_C[lrow + 16 * Rw], aw1 = s_C[lrow + 4 * tmLd + 16 * Rw];
+      const double av0 = s_C[lrow + 16 * Rv], av1 = s_C[lrow + 4 * tmLd + 16 * Rv];
+      double bq[tmTiles][2];
+      static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        const int C = t <= wv ? t : t - wv - 1;
+        bq[t][0] = s_W[lrow + 16 * C];
+        bq[t][1] = s_W[lrow + 4 * tmLd + 16 * C];
+      });
+      // every tile, also those wholly in the identity padding (their operands are zero): no branch
+      // between the tiles, so the 34 matrix instructions of a wave issue back to back
+      static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        const bool first = t <= wv;
+        const double a0 = first ? aw0 : av0, a1 = first ? aw1 : av1;
+        acc_t acc = {tl[t][0], tl[t][1], tl[t][2], tl[t][3]};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bq[t][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bq[t][1], acc, 0, 0, 0);
+        tl[t][0] = acc[0]; tl[t][1] = acc[1]; tl[t][2] = acc[2]; tl[t][3] = acc[3];
+      });
+    }
     static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
       const int R = t <= wv ? wv : tmNB - 1 - wv, C = t <= wv ? t : t - wv - 1;
-      if (livemask & (1u << t)) {              // (tiles wholly in the padding never change)
-        const double a0 = s_C[lrow + 16 * R], a1 = s_C[lrow + 4 * tmLd + 16 * R];
-        const double b0 = s_W[lrow + 16 * C], b1 = s_W[lrow + 4 * tmLd + 16 * C];
-        acc_t acc = {tl[t][0], tl[t][1], tl[t][2], tl[t][3]};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-        tl[t][0] = acc[0]; tl[t][1] = acc[1]; tl[t][2] = acc[2]; tl[t][3] = acc[3];
-      }
       if (rowmask & (1u << t)) {                // pivot rows of this tile
-        tl[t][2 * h] = s_R[lrow + 16 * C];
-        tl[t][2 * h + 1] = s_R[lrow + 4 * tmLd + 16 * C];
+        tl[t][2 * h] = s_F[lrow + 16 * C];
+        tl[t][2 * h + 1] = s_F[lrow + 4 * tmLd + 16 * C];
       }
       if (colmask & (1u << t)) {                // pivot columns: the signed transpose of the rows
         if ((ml >> 3) == h) {
@@ -264,14 +276,15 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
             const int il = g + 4 * r, i = 16 * R + il;
             const bool pivot_row = (R == Ib) && ((il >> 3) == h);
             if (!pivot_row) {
-              const double rv = s_R[(ml & 7) * tmLd + i];
+              const double rv = s_F[(ml & 7) * tmLd + i];
               tl[t][r] = (i < k0) ? rv : -rv;
             }
           }
         }
       }
     });
-    __syncthreads();                   // everyone is done with the panels
+    // no barrier here: the next pass's step (1) writes s_R only, which nobody reads any more, and
+    // its barrier separates this pass's readers of s_W / s_C / s_F from the next pass's writers
     TM_STAMP(4);
   };
   for (int kb = 0; kb < N; kb += 2 * tmB) {
