@@ -61,6 +61,7 @@ SIGNATURES = {
     "gp_hessian_f64": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_hessian_f32": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_reconstruct_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int]),
+    "gp_mv_predict_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "gp_frag_index": (c_int, [c_int, c_int, c_int, c_int]),
     "gp_likelihood_batch_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -265,7 +266,7 @@ class Context:
         check(self.lib.gp_memcpy_h2d(self.h, dptr, _ptr(arr), arr.nbytes), "gp_memcpy_h2d")
 
     def to_host(self, dptr, shape, dtype):
-        out = np.empty(shape, dtype=dtype)
+        out = self.out_pool.take(shape, dtype)      # >= 1 MB: recycled memory (see OutputPool)
         if out.nbytes:
             check(self.lib.gp_memcpy_d2h(self.h, _ptr(out), dptr, out.nbytes), "gp_memcpy_d2h")
         return out

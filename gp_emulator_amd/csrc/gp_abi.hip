@@ -1124,6 +1124,73 @@ static int hessian_host(gp_ctx* ctx, const T* expX, const T* inputs, const T* in
   return hessian_host_model<T>(ctx, m, testing, hess, M);
 }
 
+// out[r][band] = sum_p coef[p][r] basis[p][band] on `stream` (gp_reconstruct_kernel.hpp)
+static int reconstruct_on(gp_ctx* ctx, int dtype, const void* d_basis, const void* d_coef, void* d_out,
+                          int64_t n_rows, int n_pcs, int n_bands, hipStream_t stream) {
+  if (n_rows < 0 || n_pcs <= 0 || n_bands <= 0) return fail(GP_ERR_INVALID, "bad sizes");
+  if (n_pcs > 16) return fail(GP_ERR_UNSUPPORTED, "reconstruction kernels are compiled for n_pcs <= 16");
+  if (n_rows == 0) return GP_OK;
+  if (!d_basis || !d_coef || !d_out) return fail(GP_ERR_INVALID, "null device pointer");
+  if (dtype != GP_F32 && dtype != GP_F64) return fail(GP_ERR_INVALID, "bad dtype %d", dtype);
+  // geometry: rows that one 512-thread workgroup can cover whole (and that a 256-thread one
+  // cannot) use the wide form; GP_RECON_WIDE=0/1 overrides for A/B measurements
+  const int vec = dtype == GP_F64 ? 2 : 4;
+  int wide = (n_bands > 256 * 2 * vec && n_bands <= 512 * 3 * vec) ? 1 : 0;
+  if (const char* ev = getenv("GP_RECON_WIDE")) wide = atoi(ev) != 0;
+  hipError_t e;
+  if (dtype == GP_F64) {
+    gpk::ReconArgs<double> a{(const double*)d_basis, (const double*)d_coef, (double*)d_out, n_rows, n_pcs, n_bands};
+    e = gpk::launch_reconstruct_f64(a, wide, ctx->compute_units, stream);
+  } else {
+    gpk::ReconArgs<float> a{(const float*)d_basis, (const float*)d_coef, (float*)d_out, n_rows, n_pcs, n_bands};
+    e = gpk::launch_reconstruct_f32(a, wide, ctx->compute_units, stream);
+  }
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "reconstruct kernel launch: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
+// MultivariateEmulator.predict in ONE call (the latency path: an optimiser asks for one state
+// vector at a time, multivariate_gp.py:195-222): rows up, the batched predict of all principal
+// components, reconstruction and Jacobian on the device, results down, one synchronisation.
+// Work buffers come from the context's grow-only device scratch; the copies go straight between
+// the caller's arrays and the device (for these sizes the runtime's own pageable path beats a
+// staged copy: 61 us against 200 us for 2.6 MB of Jacobians).
+constexpr size_t kMvResultMax = (size_t)1 << 30;      // bytes of results per call
+template <typename T>
+static int mv_predict_host(gp_ctx* ctx, const gp_model* m, const T* d_basis, const T* y, int64_t M,
+                           int n_bands, T* fwd, T* jac) {
+  const int D = m->n_inputs, P = m->n_emulators;
+  const size_t n_y = (size_t)M * D, n_gp = (size_t)P * M * (2 + D);
+  const size_t n_fwd = (size_t)M * n_bands, n_jac = jac ? (size_t)M * D * n_bands : 0;
+  if ((n_fwd + n_jac) * sizeof(T) > kMvResultMax)
+    return fail(GP_ERR_UNSUPPORTED, "gp_mv_predict_host returns at most %zu MiB per call: split the rows", kMvResultMax >> 20);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = ensure_scratch(ctx, (n_y + n_gp + n_fwd + n_jac) * sizeof(T));
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  T* d_y = (T*)ctx->scratch;
+  T* d_mu = d_y + n_y;
+  T* d_var = d_mu + (size_t)P * M;
+  T* d_der = d_var + (size_t)P * M;
+  T* d_fwd = d_y + n_y + n_gp;
+  T* d_jac = d_fwd + n_fwd;
+  HIP_TRY(hipMemcpyAsync(d_y, y, n_y * sizeof(T), hipMemcpyHostToDevice, st));
+  rc = predict_device<T>(ctx, m, d_y, d_mu, d_var, d_der, M, GP_DERIV_ROWMAJOR, st);
+  const int dtype = sizeof(T) == 8 ? GP_F64 : GP_F32;
+  if (!rc) rc = reconstruct_on(ctx, dtype, d_basis, d_mu, d_fwd, M, P, n_bands, st);
+  if (!rc && jac) rc = reconstruct_on(ctx, dtype, d_basis, d_der, d_jac, M * D, P, n_bands, st);
+  hipError_t e = hipSuccess;
+  const bool one_copy = jac == fwd + n_fwd;             // the caller laid fwd and jac out back to back
+  if (!rc) e = hipMemcpyAsync(fwd, d_fwd, (n_fwd + (one_copy ? n_jac : 0)) * sizeof(T), hipMemcpyDeviceToHost, st);
+  if (!rc && e == hipSuccess && jac && !one_copy)
+    e = hipMemcpyAsync(jac, d_jac, n_jac * sizeof(T), hipMemcpyDeviceToHost, st);
+  const hipError_t es = hipStreamSynchronize(st);       // whatever happened, leave the stream idle
+  if (rc) return rc;
+  if (e != hipSuccess || es != hipSuccess)
+    return fail(GP_ERR_HIP, "mv predict: %s", hipGetErrorString(e != hipSuccess ? e : es));
+  return GP_OK;
+}
+
 extern "C" {
 
 int gp_model_create_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
@@ -1311,27 +1378,21 @@ int gp_predict_rows_f32(gp_ctx* ctx, const float* expX, const float* inputs, con
 int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const void* d_coef,
                           void* d_out, int64_t n_rows, int n_pcs, int n_bands) {
   if (!ctx) return fail(GP_ERR_INVALID, "null context");
-  if (n_rows < 0 || n_pcs <= 0 || n_bands <= 0) return fail(GP_ERR_INVALID, "bad sizes");
-  if (n_pcs > 16) return fail(GP_ERR_UNSUPPORTED, "reconstruction kernels are compiled for n_pcs <= 16");
-  if (n_rows == 0) return GP_OK;
-  if (!d_basis || !d_coef || !d_out) return fail(GP_ERR_INVALID, "null device pointer");
-  if (dtype != GP_F32 && dtype != GP_F64) return fail(GP_ERR_INVALID, "bad dtype %d", dtype);
   HIP_TRY(hipSetDevice(ctx->device));
-  // geometry: rows that one 512-thread workgroup can cover whole (and that a 256-thread one
-  // cannot) use the wide form; GP_RECON_WIDE=0/1 overrides for A/B measurements
-  const int vec = dtype == GP_F64 ? 2 : 4;
-  int wide = (n_bands > 256 * 2 * vec && n_bands <= 512 * 3 * vec) ? 1 : 0;
-  if (const char* ev = getenv("GP_RECON_WIDE")) wide = atoi(ev) != 0;
-  hipError_t e;
-  if (dtype == GP_F64) {
-    gpk::ReconArgs<double> a{(const double*)d_basis, (const double*)d_coef, (double*)d_out, n_rows, n_pcs, n_bands};
-    e = gpk::launch_reconstruct_f64(a, wide, ctx->compute_units, ctx->stream);
-  } else {
-    gpk::ReconArgs<float> a{(const float*)d_basis, (const float*)d_coef, (float*)d_out, n_rows, n_pcs, n_bands};
-    e = gpk::launch_reconstruct_f32(a, wide, ctx->compute_units, ctx->stream);
-  }
-  if (e != hipSuccess) return fail(GP_ERR_HIP, "reconstruct kernel launch: %s", hipGetErrorString(e));
-  return GP_OK;
+  return reconstruct_on(ctx, dtype, d_basis, d_coef, d_out, n_rows, n_pcs, n_bands, ctx->stream);
+}
+
+int gp_mv_predict_host(gp_ctx* ctx, const gp_model* model, const void* d_basis, const void* y,
+                       int64_t n_rows, int n_bands, void* fwd, void* jac) {
+  if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
+  if (n_rows < 0 || n_bands <= 0) return fail(GP_ERR_INVALID, "bad sizes");
+  if (n_rows == 0) return GP_OK;
+  if (!d_basis || !y || !fwd) return fail(GP_ERR_INVALID, "null pointer");
+  if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  if (!model->d_frags) return fail(GP_ERR_INVALID, "model was created without invQ: no variance operand");
+  if (model->dtype == GP_F64)
+    return guarded([&] { return mv_predict_host<double>(ctx, model, (const double*)d_basis, (const double*)y, n_rows, n_bands, (double*)fwd, (double*)jac); });
+  return guarded([&] { return mv_predict_host<float>(ctx, model, (const float*)d_basis, (const float*)y, n_rows, n_bands, (float*)fwd, (float*)jac); });
 }
 
 int gp_likelihood_batch_f64(gp_ctx* ctx, int n_sets, const double* theta, const double* inputs,

@@ -117,14 +117,25 @@ class MultivariateEmulator(object):
 
     def predict(self, y, do_deriv=True, is_gpu=False):
         """Reconstructed output and its Jacobian at ONE input vector ``y`` (reference
-        :195-222): ``fwd (N_full,)`` and ``deriv (N_params, N_full)``.  ``is_gpu`` is handed
-        to every per-PC ``GaussianProcess.predict`` exactly as the reference does (:215)."""
-        fwd = np.zeros(self.basis_functions[0].shape[0])
+        :195-222): ``fwd (N_full,)`` and ``deriv (N_params, N_full)``.  The numpy branch is the
+        reference's loop over the per-PC emulators.  ``is_gpu=True`` -- the call an optimiser makes
+        once per state vector -- runs on the device-resident form of the whole emulator
+        (``predict_many`` on one row: all PCs in one launch, reconstruction and Jacobian on the
+        device) instead of handing the flag to each per-PC ``predict`` as the reference does
+        (:215): same numbers, one round trip instead of ``n_pcs``."""
         y = np.atleast_2d(y)
+        if is_gpu:
+            if y.shape[0] != 1:
+                raise ValueError("predict takes one input vector; predict_many takes rows")
+            if do_deriv:
+                fwd, jac = self.predict_many(y, is_gpu=True, do_deriv=True)
+                return fwd[0], jac[0]
+            return self.predict_many(y, is_gpu=True)[0]
+        fwd = np.zeros(self.basis_functions[0].shape[0])
         if do_deriv:
             deriv = np.zeros((y.shape[1], self.basis_functions.shape[1]))
         for i in range(self.n_pcs):
-            pred_mu, pred_var, grad = self.emulators[i].predict(y, is_gpu=is_gpu)
+            pred_mu, pred_var, grad = self.emulators[i].predict(y)
             fwd += pred_mu * self.basis_functions[i]
             if do_deriv:
                 deriv += np.asarray(grad).T @ np.atleast_2d(self.basis_functions[i])
@@ -132,13 +143,60 @@ class MultivariateEmulator(object):
             return fwd.squeeze(), deriv
         return fwd.squeeze()
 
+    # ---- the emulator resident on the device ----------------------------------------------------
+    def _fingerprint(self):
+        """What the device-resident copy was made from, cheap enough for the per-call check of a
+        latency path: the identity of every emulator and of its invQ, and the bytes of theta and
+        invQt (any legitimate re-training changes invQt with invQ).  After editing an emulator's
+        arrays IN PLACE call ``release_gpu()``."""
+        return tuple((id(gp), id(gp.invQ), np.asarray(gp.theta).tobytes(), np.asarray(gp.invQt).tobytes())
+                     for gp in self.emulators) + (id(self.basis_functions),)
+
+    def _gpu_state(self, dt):
+        from . import _lib, perband
+        cache = self.__dict__.setdefault("_gpu", {})
+        key = (dt.str, _lib.default_device())
+        fp = self._fingerprint()
+        st = cache.get(key)
+        if st is not None and st["fp"] == fp:
+            return st
+        if st is not None:
+            self._release(st)
+            del cache[key]
+        batch = perband.make_batch(self.emulators, dt)
+        ctx = batch.ctx
+        st = {"fp": fp, "batch": batch, "ctx": ctx,
+              "d_basis": ctx.to_device(np.ascontiguousarray(self.basis_functions, dtype=dt))}
+        cache[key] = st
+        return st
+
+    @staticmethod
+    def _release(st):
+        st["ctx"].free(st["d_basis"])
+        st["batch"].close()
+
+    def release_gpu(self):
+        """Free the device-resident copy (packed emulators, basis); the next
+        ``is_gpu=True`` call rebuilds it."""
+        for st in self.__dict__.get("_gpu", {}).values():
+            self._release(st)
+        self.__dict__["_gpu"] = {}
+
+    def __del__(self):
+        try:
+            self.release_gpu()
+        except Exception:
+            pass
+
     def predict_many(self, Y, is_gpu=True, precision=np.float64, do_deriv=False):
         """Beyond the reference (whose predict breaks for more than one row, SURVEY.md
         section 3.3): reconstructed outputs ``(M, N_full)`` -- and with ``do_deriv`` the
         Jacobians ``(M, N_params, N_full)`` -- for M input rows.  On the GPU the n_pcs
         emulators run as ONE batched launch over the shared rows and the reconstruction
         ``sum_pc mu_pc * basis_pc`` is a second kernel on the resident outputs; only the
-        reconstructed arrays cross PCIe."""
+        reconstructed arrays cross PCIe.  The packed emulators and the basis stay on the device
+        between calls (``release_gpu()`` frees them), and a call is one library call
+        (``gp_mv_predict_host``): rows up, three launches, results down."""
         Y = np.atleast_2d(Y)
         M, D = Y.shape
         B = self.basis_functions.shape[1]
@@ -149,28 +207,24 @@ class MultivariateEmulator(object):
                 return fwd
             grads = np.stack([o[2] for o in out])                  # (P, M, D)
             return fwd, np.einsum("pmd,pb->mdb", grads, self.basis_functions)
-        from . import _lib, perband
+        from . import _lib
         dt = np.dtype(precision)
-        batch = perband.make_batch(self.emulators, dt)
-        ctx = batch.ctx
-        P, isz = self.n_pcs, dt.itemsize
-        bufs = []
-        try:
-            d_y = ctx.to_device(np.ascontiguousarray(Y, dtype=dt)); bufs.append(d_y)
-            d_mu = ctx.malloc(P * M * isz); bufs.append(d_mu)
-            d_var = ctx.malloc(P * M * isz); bufs.append(d_var)
-            d_der = ctx.malloc(P * M * D * isz); bufs.append(d_der)
-            d_basis = ctx.to_device(np.ascontiguousarray(self.basis_functions, dtype=dt)); bufs.append(d_basis)
-            batch.predict_device(d_y, d_mu, d_var, d_der, M, _lib.GP_DERIV_ROWMAJOR)
-            d_fwd = ctx.malloc(M * B * isz); bufs.append(d_fwd)
-            ctx.reconstruct_device(dt, d_basis, d_mu, d_fwd, M, P, B)
-            fwd = ctx.to_host(d_fwd, (M, B), dt)
-            if not do_deriv:
-                return fwd
-            d_jac = ctx.malloc(M * D * B * isz); bufs.append(d_jac)
-            ctx.reconstruct_device(dt, d_basis, d_der, d_jac, M * D, P, B)
-            return fwd, ctx.to_host(d_jac, (M, D, B), dt)
-        finally:
-            for b in bufs:
-                ctx.free(b)
-            batch.close()
+        st = self._gpu_state(dt)
+        ctx, batch = st["ctx"], st["batch"]
+        isz = dt.itemsize
+        Yc = np.ascontiguousarray(Y, dtype=dt)
+        # one library call per <= 1 GiB of results (rows up, three launches, results down, one
+        # synchronisation): a single call for anything an optimiser asks for
+        step = max(1, (1 << 30) // (B * (1 + (D if do_deriv else 0)) * isz))
+        if do_deriv and M <= step:                         # one call: fwd and jac back to back, one copy down
+            both = ctx.out_pool.take((M * B * (1 + D),), dt)   # >= 1 MB: recycled memory (see _lib.OutputPool)
+            fwd, jac = both[:M * B].reshape(M, B), both[M * B:].reshape(M, D, B)
+        else:
+            fwd = ctx.out_pool.take((M, B), dt)
+            jac = ctx.out_pool.take((M, D, B), dt) if do_deriv else None
+        for r0 in range(0, M, step):
+            r1 = min(M, r0 + step)
+            _lib.check(ctx.lib.gp_mv_predict_host(ctx.h, batch.h, st["d_basis"], _lib._ptr(Yc[r0:r1]), r1 - r0, B,
+                                                  _lib._ptr(fwd[r0:r1]), _lib._ptr(jac[r0:r1]) if do_deriv else None),
+                       "gp_mv_predict_host")
+        return (fwd, jac) if do_deriv else fwd

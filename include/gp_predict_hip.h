@@ -207,6 +207,17 @@ int gp_hessian_f32(gp_ctx* ctx, const float* expX, const float* inputs, const fl
 int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const void* d_coef,
                           void* d_out, int64_t n_rows, int n_pcs, int n_bands);
 
+/* MultivariateEmulator.predict (gp_emulator/multivariate_gp.py:195-222) in one call, for the
+ * caller that asks for one state vector (or a few) at a time: `model` is the batch of the n_pcs
+ * per-PC emulators (gp_batch_create_*), d_basis their basis functions [n_pcs][n_bands] on the
+ * device (model's dtype), y host rows [n_rows][n_inputs].  Fills host arrays fwd [n_rows][n_bands]
+ * and, unless jac is NULL, jac [n_rows][n_inputs][n_bands]: rows up, batched predict,
+ * reconstruction and Jacobian on the device, results down (one copy when jac == fwd +
+ * n_rows * n_bands, i.e. the two arrays are laid out back to back), one synchronisation.  At most 1 GiB
+ * of results per call (GP_ERR_UNSUPPORTED beyond: split the rows). */
+int gp_mv_predict_host(gp_ctx* ctx, const gp_model* model, const void* d_basis, const void* y,
+                       int64_t n_rows, int n_bands, void* fwd, void* jac);
+
 /* ---- training objective (next after the predict path: SURVEY.md 8f rank 2) -------------------
  * For each of n_sets hyper-parameter vectors theta [n_sets][n_inputs+2]: what
  * GaussianProcess.loglikelihood + partial_devs compute (gp_emulator/GaussianProcess.py:52-125):

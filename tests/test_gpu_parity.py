@@ -786,6 +786,48 @@ def test_set_params_on_gpu_matches_host(gpu_lib):
     assert e_mu <= 1e-8 and e_der <= 1e-8 and e_var <= 1e-7   # numpy's own inverse is 2e-10 off
 
 
+def test_multivariate_predict_latency_path_and_resident_state(gpu_lib):
+    """predict(y, is_gpu=True) -- one state vector per call, what an optimiser does -- runs on the
+    device-resident emulator through ONE library call (gp_mv_predict_host).  Same numbers as the
+    numpy loop, and row for row the same whatever else is in the call; the resident copy follows
+    the emulators when they are re-set and is freed on request."""
+    from gp_emulator_amd import MultivariateEmulator
+    g = load_golden("prosail_mv")
+    X = g["train_data"].T @ g["basis_functions"]
+    mv = MultivariateEmulator(X=X, y=g["y_train"], hyperparams=g["hyperparams"],
+                              basis_functions=g["basis_functions"], n_pcs=int(g["n_pcs"]))
+    rs = np.random.RandomState(8)
+    lo, hi = g["y_train"].min(0), g["y_train"].max(0)
+    Y = lo + (hi - lo) * rs.random_sample((300, lo.size))
+    f_cpu, j_cpu = mv.predict(Y[0])
+    f_gpu, j_gpu = mv.predict(Y[0], is_gpu=True)
+    assert f_gpu.shape == f_cpu.shape and j_gpu.shape == j_cpu.shape
+    assert np.max(np.abs(f_gpu - f_cpu)) <= 1e-10 * np.max(np.abs(f_cpu))
+    assert np.max(np.abs(j_gpu - j_cpu)) <= 1e-9 * np.max(np.abs(j_cpu))
+    assert np.array_equal(mv.predict(Y[0], do_deriv=False, is_gpu=True), f_gpu)
+    with pytest.raises(ValueError):
+        mv.predict(Y[:2], is_gpu=True)
+    # 300 rows with Jacobians (55 MB of results): rows agree bit for bit with small calls
+    f_all, j_all = mv.predict_many(Y, do_deriv=True)
+    f_few, j_few = mv.predict_many(Y[:7], do_deriv=True)
+    assert np.array_equal(f_all[:7], f_few) and np.array_equal(j_all[:7], j_few)
+    assert np.array_equal(f_all[0], f_gpu) and np.array_equal(j_all[0], j_gpu)
+    assert mv.predict_many(Y[:0]).shape == (0, X.shape[1])
+    # the resident copy is reused, follows a re-set emulator, and can be dropped
+    st = list(mv._gpu.values())[0]
+    mv.predict(Y[1], is_gpu=True)
+    assert list(mv._gpu.values())[0] is st
+    gp0 = mv.emulators[0]
+    gp0._set_params(gp0.theta + 0.05)
+    f_new = mv.predict(Y[0], do_deriv=False, is_gpu=True)
+    assert list(mv._gpu.values())[0] is not st
+    assert np.max(np.abs(f_new - mv.predict(Y[0], do_deriv=False))) <= 1e-10 * np.max(np.abs(f_new))
+    assert np.max(np.abs(f_new - f_gpu)) > 1e-6 * np.max(np.abs(f_gpu))
+    mv.release_gpu()
+    assert mv._gpu == {}
+    assert np.array_equal(mv.predict(Y[0], do_deriv=False, is_gpu=True), f_new)
+
+
 def test_multivariate_set_up_on_gpu_and_storage(gpu_lib, tmp_path):
     """All n_pcs inverses in one launch; the emulator then predicts as the host-built one does;
     EmulatorStorage.get_emulator(is_gpu=True) takes the same route."""
