@@ -393,8 +393,12 @@ class Model:
         lead = () if E is None else (E,)
         dshape = lead + ((M, D) if deriv_layout == GP_DERIV_ROWMAJOR else (D, M))
         if out is None:
-            take = self.ctx.out_pool.take
-            mu, var, deriv = take(lead + (M,), hdt), take(lead + (M,), hdt), take(dshape, hdt)
+            # one buffer, three views: the library brings a small call's results back in one copy
+            # when result | error | deriv lie back to back
+            n_e = (E or 1) * M
+            flat = self.ctx.out_pool.take((n_e * (2 + D),), hdt)
+            mu, var = flat[:n_e].reshape(lead + (M,)), flat[n_e:2 * n_e].reshape(lead + (M,))
+            deriv = flat[2 * n_e:].reshape(dshape)
         else:
             mu, var, deriv = out
             for a, shape in ((mu, lead + (M,)), (var, lead + (M,)), (deriv, dshape)):
