@@ -125,6 +125,9 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
         obj = os.path.join(OBJ, "generic_%s.o" % tname)
         tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
                                         os.path.join(CSRC, "gp_generic_tu.hip"), "-o", obj])
+        obj = os.path.join(OBJ, "few_%s.o" % tname)
+        tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
+                                        os.path.join(CSRC, "gp_few_tu.hip"), "-o", obj])
         obj = os.path.join(OBJ, "hess_%s.o" % tname)
         tasks.append([HIPCC] + FLAGS + defines + ["-DGP_T=" + ctype, "-DGP_TNAME=" + tname, "-c",
                                         os.path.join(CSRC, "gp_hessian_tu.hip"), "-o", obj])

