@@ -22,10 +22,11 @@
 //     instructions back to back, no branch between the tiles); finally the finished pivot rows /
 //     columns (a third panel, s_F) replace the corresponding registers.  Two barriers per pass:
 //     the next pass stages its pivot rows into s_R, which the update phase never reads;
-//   * Q itself is built straight into the tiles, the finished inverse is written to global
-//     memory once (both triangles) for invQt and the caller, and the gradient sums
-//     (likelihood_grad_kernel's work) follow in the same kernel from that L2-hot copy: one kernel
-//     per evaluation, half the pairs (the lower triangle).
+//   * Q itself is built straight into the tiles; invQt = invQ t is summed from the finished tiles in
+//     registers (row sums inside the owning wave, column sums through a per-wave LDS strip, added in
+//     wave order); the lower triangle of the inverse is written to global memory once (the mirror
+//     image too when the caller wants the matrix) and the gradient sums (likelihood_grad_kernel's
+//     work) follow in the same kernel from that L2-hot copy: one kernel per evaluation, half the pairs.
 //
 // Work per theta: 32 passes x 17 tiles x 2 matrix instructions per wave; the per-pass panel steps
 // are latency-bound and run on one wave / 256 threads while the others wait at the barrier.
@@ -292,9 +293,9 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
     if (kb + tmB < N) pass(kb + tmB, std::integral_constant<int, 1>{});
   }
 
-  // ---- the inverse -> global memory ------------------------------------------------------------------
-  // The lower triangle in 128-byte runs; the mirror image (8-byte stores, a row apart) only when
-  // the caller wants the whole matrix back.
+  __syncthreads();                     // the last pass's readers of the panels are done
+  // ---- the inverse -> global memory: the lower triangle in 128-byte runs (the gradient sums below read
+  // it back from L2); the mirror image (8-byte stores, a row apart) only when the caller wants the matrix
   const bool full = p.full_inverse != 0;
   static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;
@@ -309,43 +310,60 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
       }
     }
   });
-  __syncthreads();
 
-  // ---- invQt = invQ t from the lower triangle L: one coalesced sweep over its rows, row sums
-  // reduced across the wave, column sums kept per lane (column j = lane + 64 m) and combined
-  // across the waves through LDS;  cost ------------------------------------------------------------
+  // ---- invQt = invQ t straight from the register tiles ------------------------------------------------
+  // Tile (R, C), lane (g, ml), register r is element (i = 16 R + g + 4 r, j = 16 C + ml).  A tile gives
+  // its rows sum_j v_ij t_j and, below the diagonal, its columns sum_i v_ij t_i (the mirror image);
+  // diagonal tiles hold both triangles and give rows only.  A block row belongs to one wave, so its row
+  // sums are finished inside the wave (accumulated over the tiles per lane, reduced over the 16 lanes of
+  // a group at the end); column sums go to a per-wave strip in LDS (s_W) and are added in wave order.
   {
-    double colacc[tmNP / 64];
+    double* colw = s_W + w * tmNP;
+    for (int i = lane; i < tmNP; i += 64) colw[i] = 0.0;
+    double rowA[4] = {0.0, 0.0, 0.0, 0.0}, rowB[4] = {0.0, 0.0, 0.0, 0.0};   // block rows w and 15 - w
+    static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      int wv = w;
+      asm volatile("" : "+s"(wv));                     // (per-tile addresses are not to be hoisted: see pass)
+      const int R = t <= wv ? wv : tmNB - 1 - wv, C = t <= wv ? t : t - wv - 1;
+      const double tj = s_vec[16 * C + ml];
+      double cs = 0.0;
 #pragma unroll
-    for (int m = 0; m < tmNP / 64; ++m) colacc[m] = 0.0;
-    for (int i = w; i < N; i += tmThreads / 64) {
-      const double ti = s_vec[i];
-      double s = 0.0;
-#pragma unroll
-      for (int m = 0; m < tmNP / 64; ++m) {
-        const int j = lane + 64 * m;
-        if (j <= i) {
-          const double v = A[(long long)i * N + j];
-          s = fma(v, s_vec[j], s);
-          if (j < i) colacc[m] = fma(v, ti, colacc[m]);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const double v = tl[t][r];
+        if (t <= wv) rowA[r] = fma(v, tj, rowA[r]);
+        else rowB[r] = fma(v, tj, rowB[r]);
+        cs = fma(v, s_vec[16 * R + g + 4 * r], cs);
       }
+      if (R != C) {
+        cs = xor_reduce_groups(cs);                    // over the lane groups: the 16 rows of the tile
+        if (g == 0) colw[16 * C + ml] += cs;           // (this wave's strip: plain read-modify-write)
+      }
+      asm volatile("" ::: "memory");                   // one tile at a time: keeps the live set small
+    });
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (lane == 0) s_a[i] = s;                      // row part (the diagonal included)
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        rowA[r] += __shfl_xor(rowA[r], o, 64);
+        rowB[r] += __shfl_xor(rowB[r], o, 64);
+      }
     }
+    if (ml == 0) {
 #pragma unroll
-    for (int m = 0; m < tmNP / 64; ++m) s_W[w * tmNP + lane + 64 * m] = colacc[m];
+      for (int r = 0; r < 4; ++r) {
+        s_R[16 * w + g + 4 * r] = rowA[r];
+        s_R[16 * (tmNB - 1 - w) + g + 4 * r] = rowB[r];
+      }
+    }
   }
   __syncthreads();
   if (tid < tmNP) {
-    double s = s_a[tid];
+    double s = s_R[tid];
 #pragma unroll
     for (int k = 0; k < tmThreads / 64; ++k) s += s_W[k * tmNP + tid];
-    s_R[tid] = s;
+    s_a[tid] = s;
   }
-  __syncthreads();
-  if (tid < tmNP) s_a[tid] = s_R[tid];
   __syncthreads();
   double tq = 0.0, ld = 0.0;
   for (int i = tid; i < N; i += tmThreads) {
@@ -359,13 +377,14 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
   // With c_ij = (invQt_i invQt_j - invQ_ij) Z_ij (gp_train_kernel.hpp, gradient_sums):
   //   dcost/dtheta_d = e_d / 4 sum_ij c_ij (x_id - x_jd)^2,  dcost/dtheta_D = -1/2 sum_ij c_ij,
   //   dcost/dtheta_D+1 = 1/2 e_{D+1} (tr invQ - invQt.invQt).
-  // Over the lower triangle only (an off-diagonal pair counts twice), invQ read back from the
-  // L2-hot copy this workgroup has just written.  A rolled loop on purpose: unrolled over the
-  // register tiles the 68 elements per lane are scheduled against each other and spill by the
-  // thousand.
+  // Over the lower triangle only (an off-diagonal pair counts twice), invQ read back from the L2-hot
+  // copy this workgroup has just written: wave w takes rows w, w + 8, ...; a lane the columns lane,
+  // lane + 64, ... of a row.  A rolled loop on purpose: from the register tiles instead, the 136 tile
+  // registers + the DM accumulators + a row's and a column's coordinates do not fit (2 000 spilled
+  // registers), and loading the next row while the current one is worked on was measured slower.
   double acc[DM];
   static_for<DM>([&](auto dc) __attribute__((always_inline)) { acc[decltype(dc)::value] = 0.0; });
-  double sumc = 0.0, tr = 0.0, ss = 0.0;
+  double sumc = 0.0, tr = 0.0, ss = 0.0;      // (the barriers of the invQt step also cover the write-out above)
   for (int i = w; i < N; i += tmThreads / 64) {
     const double ai = s_a[i];
     for (int j = lane; j <= i; j += 64) {
