@@ -31,6 +31,36 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.gp_version_string()
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/gp_predict_hip.h compiles as strict C99 and a C program
+    links against the library and calls it (device count, error string, version) -- no C++, no
+    Python in between.  What a cgo / JNI / ctypes binding relies on."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "cabi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "gp_predict_hip.h"\n'
+        "int main(void) {\n"
+        "  int n = -1; gp_ctx* ctx = NULL;\n"
+        "  int rc = gp_device_count(&n);\n"
+        '  if (strstr(gp_version_string(), "gfx950") == NULL) return 2;\n'
+        "  if (rc == GP_OK && n > 0) return 0;               /* a GPU box: nothing more to check here */\n"
+        "  rc = gp_ctx_create(0, &ctx);                        /* no GPU: must fail, loudly */\n"
+        "  if (rc == GP_OK || ctx != NULL) return 3;\n"
+        "  if (strlen(gp_last_error_string()) == 0) return 4;\n"
+        '  printf("%d %s\\n", rc, gp_last_error_string());\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "cabi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH),
+                    "-Wl,-rpath," + libdir], check=True, timeout=120)
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+
+
 def test_no_gpu_fails_loudly_not_silently():
     """On a box without a GPU is_gpu=True must raise, never compute on the CPU."""
     if _lib.device_count() > 0:
