@@ -26,13 +26,65 @@ def make_batch(gps, precision=np.float64, device=None):
     return _lib.BatchModel(_lib.default_context(device), expX, inputs, invQt, invQ, precision)
 
 
-def predict_bands(gps, testing, precision=np.float64, device=None):
-    """mu (E, M), var (E, M), deriv (E, M, D) for the E emulators in ``gps``."""
-    batch = make_batch(gps, precision, device)
-    try:
-        return batch.predict(np.asarray(testing))
-    finally:
-        batch.close()
+def predict_bands(gps, testing, precision=np.float64, device=None, devices=None, predict_fn=None):
+    """mu (E, M), var (E, M), deriv (E, M, D) for the E emulators in ``gps``.
+
+    ``devices`` (a list of device ids) shards the EMULATORS over the GPUs of a node -- BASELINE
+    config 3's other partition: GPU g takes a contiguous block of the E
+    bands with the shared test rows replicated (8.8 MB for 1e5 rows) instead of every GPU holding
+    all E inverses (1 GB for 2101 bands).  One Python thread and one context per device (the C
+    ABI releases the GIL), every device's slab pipeline writing its own ``[e0:e1]`` slice of the
+    three output arrays: a host gather, no collective.  ``predict_fn(device, gps_block, testing)
+    -> (mu, var, deriv)`` replaces the HIP path in the CPU tests of the sharding logic."""
+    testing = np.asarray(testing)
+    if devices is None:
+        batch = make_batch(gps, precision, device)
+        try:
+            return batch.predict(testing)
+        finally:
+            batch.close()
+    import threading
+    from . import multi_gpu
+    if not gps:
+        raise ValueError("need at least one GaussianProcess")
+    E, (M, D) = len(gps), testing.shape
+    dt = np.float64 if (testing.dtype == np.float64 or np.dtype(precision) == np.float64) else np.float32
+    mu, var, deriv = np.empty((E, M), dt), np.empty((E, M), dt), np.empty((E, M, D), dt)
+    blocks = multi_gpu.row_shards(E, len(devices))       # contiguous blocks of emulators
+    errors = []
+
+    def work(dev, e0, e1):
+        try:
+            if e1 <= e0:
+                return
+            if predict_fn is not None:
+                mu[e0:e1], var[e0:e1], deriv[e0:e1] = predict_fn(dev, gps[e0:e1], testing)
+                return
+            ctx, lock = multi_gpu._device_context(dev)
+            with lock:
+                part = gps[e0:e1]
+                batch = _lib.BatchModel(ctx, np.stack([np.exp(gp.theta) for gp in part]), np.asarray(part[0].inputs),
+                                        np.stack([np.asarray(gp.invQt) for gp in part]),
+                                        np.stack([np.asarray(gp.invQ) for gp in part]), precision)
+                try:
+                    batch.predict(testing, out=(mu[e0:e1], var[e0:e1], deriv[e0:e1]))
+                finally:
+                    batch.close()
+        except BaseException as exc:          # surfaced to the caller below
+            errors.append(exc)
+
+    inputs = np.asarray(gps[0].inputs)
+    for gp in gps[1:]:
+        if np.asarray(gp.inputs).shape != inputs.shape or not np.array_equal(gp.inputs, inputs):
+            raise ValueError("per-band emulators must share the same training inputs")
+    threads = [threading.Thread(target=work, args=(dev, e0, e1)) for dev, (e0, e1) in zip(devices, blocks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return mu, var, deriv
 
 
 # ---------------------------------------------------------------------------------------------

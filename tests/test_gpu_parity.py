@@ -696,6 +696,27 @@ def test_bench_json_contract(gpu_lib):
     assert max(d["parity"]["e_mu"], d["parity"]["e_var"], d["parity"]["e_deriv"]) <= 1e-10
 
 
+def test_predict_bands_emulator_shards_on_gpu(gpu_lib):
+    """perband.predict_bands(devices=[...]): blocks of emulators on separate contexts (here three
+    on the one GPU), each writing its slice of the outputs -- bit-identical to the one-batch call."""
+    from gp_emulator_amd import perband
+    g = synthetic_case("c2_n250_d11")
+    rs = np.random.RandomState(12)
+    gps = []
+    for e in range(7):
+        gp = make_gp(g)
+        gp.theta = rs.random_sample(g["theta"].shape)
+        gp.invQ, gp.invQt = rs.random_sample(g["invQ"].shape), rs.random_sample(g["invQt"].shape)
+        gps.append(gp)
+    t = g["testing"][:777]
+    one = perband.predict_bands(gps, t)
+    cut = perband.predict_bands(gps, t, devices=[0, 0, 0])
+    for a, b in zip(one, cut):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    ref = gp_oracle.cpu_predict(g["inputs"], gps[5].theta, gps[5].invQ, gps[5].invQt, t)
+    assert max(errs(ref, [x[5] for x in cut])) <= 1e-10
+
+
 def test_predict_sharded_threads_on_gpu(gpu_lib):
     """multi_gpu.predict_sharded with the real HIP path: one thread + one context per shard
     (here three shards on the one GPU of the test box), host gather into disjoint slices."""

@@ -279,6 +279,40 @@ def test_learn_bands_worker_processes_change_nothing_but_the_wall_clock():
                             processes=2, batch_fn=broken)
 
 
+def test_predict_bands_shards_emulators_over_devices():
+    """BASELINE config 3's other partition: the EMULATORS are cut into contiguous blocks, one per
+    device, the shared test rows go to every device, and each block lands in its own slice of the
+    outputs (host gather, no collective).  The HIP path is replaced by a numpy one here."""
+    from gp_emulator_amd import GaussianProcess, perband
+    X, bands = _bands_problem(n_bands=7)
+    gps = []
+    for k, t in enumerate(bands):
+        gp = GaussianProcess(X, t)
+        gp._set_params(np.array([0.3 + 0.1 * k] * X.shape[1] + [0.5, -4.0]))
+        gps.append(gp)
+    testing = np.random.RandomState(2).random_sample((33, X.shape[1]))
+    seen = []
+
+    def fake(dev, part, rows):
+        seen.append((dev, len(part)))
+        out = [gp.predict(rows) for gp in part]
+        return np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), np.stack([o[2] for o in out])
+    mu, var, der = perband.predict_bands(gps, testing, devices=[0, 1, 2], predict_fn=fake)
+    assert sorted(seen) == [(0, 3), (1, 3), (2, 1)]
+    for e, gp in enumerate(gps):
+        m, v, d = gp.predict(testing)
+        assert np.array_equal(mu[e], m) and np.array_equal(var[e], v) and np.array_equal(der[e], d)
+    mu2 = perband.predict_bands(gps[:2], testing, devices=[0, 1, 2, 3], predict_fn=fake)[0]   # more devices than bands
+    assert np.array_equal(mu2, mu[:2])
+
+    def broken(dev, part, rows):
+        raise RuntimeError("device %d failed" % dev)
+    with pytest.raises(RuntimeError):
+        perband.predict_bands(gps, testing, devices=[0, 1], predict_fn=broken)
+    with pytest.raises(ValueError):
+        perband.predict_bands(gps + [GaussianProcess(X + 1.0, bands[0])], testing, devices=[0], predict_fn=fake)
+
+
 def test_output_pool_reuses_only_unreferenced_buffers():
     """_lib.OutputPool hands a buffer out again only when nothing but the pool refers to it: results
     a caller still holds (or views of them) are never overwritten by a later predict."""
