@@ -577,7 +577,11 @@ def main():
                 traffic = None
         ctype = "double" if a.precision == "f64" else "float"
         if hess_mfma:
-            kfull = "hessian_mfma_kernel<%s,%d,%d>" % (ctype, minfo["kernel_d"], minfo["kernel_nb"])
+            # the large fp64 instances run the windowed form (gp_hessian_win_kernel.hpp; hess_wide's rule)
+            nb_, kd_ = minfo["kernel_nb"], minfo["kernel_d"]
+            win = (a.precision == "f64" and (nb_ >= 16 or (nb_ >= 12 and kd_ >= 16))
+                   and os.environ.get("GP_HESS_WIN", "1") != "0")
+            kfull = "%s<%s,%d,%d>" % ("hessian_win_kernel" if win else "hessian_mfma_kernel", ctype, kd_, nb_)
         elif kind == "hessian":
             kfull = "hessian_kernel<%s,%d>" % (ctype, minfo["kernel_d"])
         else:

@@ -25,6 +25,7 @@
 #include "gp_generic_kernel.hpp"
 #include "gp_hessian_kernel.hpp"
 #include "gp_hessian_mfma_kernel.hpp"
+#include "gp_hessian_win_kernel.hpp"
 #include "gp_host_pool.hpp"
 #include "gp_predict_kernel.hpp"
 #include "gp_reconstruct_kernel.hpp"
@@ -625,6 +626,14 @@ hipError_t launch_hessm<double>(int knb, int kd, const gpk::HessMfmaArgs<double>
   return hipErrorInvalidValue;
 }
 
+// Large fp64 instances (hess_wide): the windowed kernel (gp_hessian_win_kernel.hpp) or, with
+// GP_HESS_WIN=0, the one-wave-per-SIMD geometry of hessian_mfma_kernel.  Read once: a model's packed
+// products follow the kernel that will read them.
+static bool hess_use_win() {
+  static const bool v = [] { const char* ev = getenv("GP_HESS_WIN"); return !ev || atoi(ev) != 0; }();
+  return v;
+}
+
 static bool hessian_on_matrix_core(const gp_model* m) {
   if (m->kernel_nb <= 0 || m->n_emulators != 1 || m->xs_host.empty()) return false;
   if (const char* ev = getenv("GP_HESS_VALU"))      // A/B switch: force the VALU kernel
@@ -644,14 +653,16 @@ static int ensure_hess_frags(gp_ctx* ctx, gp_model* m) {
   // geometry of hessian_mfma_kernel<T, kd, knb> (gpk::HGeo): wide instances take their
   // fragments in paired order and in chunks of one pair block
   const bool wide = gpk::hess_wide<T>(kd, knb);
-  const int chunk = wide ? 4 * knb : gpk::Geo<T>::kChunk;
+  const bool win = wide && hess_use_win();      // windowed kernel: k-step-major fragments, standard chunks
+  const int chunk = win ? gpk::WGeo::kChunk : wide ? 4 * knb : gpk::Geo<T>::kChunk;
   const int nblk = gpk::hess_blocks(kd);
   const size_t n = (size_t)gpk::hess_frag_count_padded(kd, knb, chunk) * 64;
   std::vector<T> fr(n, T(0));
   for (int c = 0; c < nblk; ++c)
     for (int I = 0; I < knb; ++I)
       for (int s = 0; s < 4; ++s) {
-        T* f = fr.data() + (size_t)gpk::hess_frag_index(c, I, s, knb, wide, nblk) * 64;
+        T* f = fr.data() + (size_t)(win ? gpk::hess_win_frag_index(c, I, s, nblk)
+                                        : gpk::hess_frag_index(c, I, s, knb, wide, nblk)) * 64;
         for (int l = 0; l < 64; ++l) {
           const int i = gpk::own_index<T>(I, s, l >> 4);   // slot; padding slots hold zero rows
           const int q = l & 15;             // MFMA output row = accumulator r of lane group g
@@ -689,9 +700,12 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
     h.hess = (T*)d_hess;
     h.M = M;
     h.d_actual = m->n_inputs;
-    const int kRowsPerWG = gpk::hess_wide<T>(m->kernel_d, m->kernel_nb) ? 4 * gpk::kTile : gpk::Geo<T>::kRowsPerWG;
+    const bool wide = gpk::hess_wide<T>(m->kernel_d, m->kernel_nb);
+    h.use_win = wide && hess_use_win() ? 1 : 0;
+    h.dbg = (unsigned long long*)ctx->dbg;
+    const int kRowsPerWG = wide ? 4 * gpk::kTile : gpk::Geo<T>::kRowsPerWG;      // wide and windowed: 4-wave workgroups
     const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG;
-    int64_t grid = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU;
+    int64_t grid = (int64_t)ctx->compute_units * (h.use_win ? gpk::WGeo::kWGPerCU : gpk::Geo<T>::kWGPerCU);
     if (grid > groups) grid = groups;
     hipError_t e = launch_hessm<T>(m->kernel_nb, m->kernel_d, h, (int)grid, stream);
     if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian kernel launch: %s", hipGetErrorString(e));

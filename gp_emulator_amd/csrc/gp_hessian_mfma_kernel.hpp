@@ -159,6 +159,8 @@ struct HessMfmaArgs {
   T* hess;            // [M][d_actual][d_actual]
   long long M;
   int d_actual;
+  int use_win;        // hess_wide instances: 1 = hessian_win_kernel (pfrags packed k-step-major), 0 = the wide geometry
+  unsigned long long* dbg;   // GP_STAMPS builds only (hessian_win_kernel): [8] segment cycle sums; else unused
 };
 
 // Geometry of hessian_mfma_kernel<T, D, NB> (see the header comment).

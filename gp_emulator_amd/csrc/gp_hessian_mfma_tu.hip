@@ -3,6 +3,7 @@
 // profiles/r01_hessian_kernels.txt).  Compiled by build.py with
 // -DGP_T=<float|double> -DGP_TNAME=<f32|f64> -DGP_NB=<blocks of 16 training points>.
 #include "gp_hessian_mfma_kernel.hpp"
+#include "gp_hessian_win_kernel.hpp"
 
 #define GP_CAT2(a, b, c) a##b##_##c
 #define GP_CAT(a, b, c) GP_CAT2(a, b, c)
@@ -11,6 +12,12 @@ namespace gpk {
 
 template <int D>
 static hipError_t launch_one(const HessMfmaArgs<GP_T>& a, int grid, hipStream_t stream) {
+  if constexpr (hess_wide<GP_T>(D, GP_NB)) {
+    if (a.use_win) {      // the windowed form (gp_hessian_win_kernel.hpp): k-step-major fragments, 4-wave workgroups
+      hipLaunchKernelGGL((hessian_win_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(WGeo::kThreads), 0, stream, a);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((hessian_mfma_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(HGeo<GP_T, D, GP_NB>::kThreads), 0, stream, a);
   return hipGetLastError();
 }

@@ -1,0 +1,288 @@
+// Hessian on the matrix core, WINDOWED form for the large fp64 instances (hess_wide: N > 240, or
+// N > 176 at D = 16).
+//
+// hessian_mfma_kernel walks the products block by block: one accumulator at a time runs over ALL
+// training points, so the whole weight tile of a wave's 16 rows must sit in registers through the
+// matrix phase -- 8 NB registers in fp64 (152 at N = 300), which with t'', G and a training row does
+// not fit the 256 registers of a wave at two waves per SIMD.  The wide geometry of that kernel buys
+// the registers with occupancy (one wave per SIMD, 512 registers) and pays for it: a lone wave
+// reaches 85 % of the matrix pipe and 76 % of the fp64 vector rate and has nothing to cover its own
+// LDS and barrier waits with.
+//
+// Here the ORDER is turned round instead.  The training points are taken in windows of KW k-steps
+// (4 KW points per lane group); for each window
+//   phase A   the weights of the window only (2 KW registers), s and G accumulated as before;
+//   phase B   for every k-step of the window, one matrix instruction into EACH of the NBLK block
+//             accumulators (fragments packed k-step-major: (k-step, block)) -- NBLK independent
+//             chains, no dependent issue at all.
+// All NBLK accumulators stay live (8 NBLK registers: 80 at D = 16), but the weight tile never
+// exists as a whole: 80 + 2 KW + t'' + G + a training row fit 256 registers, so the kernel runs
+// two waves per SIMD without spills.  The blocks are finished and stored after the last window.
+#pragma once
+#include "gp_hessian_mfma_kernel.hpp"
+
+#ifndef GP_HESS_WINDOWS
+#define GP_HESS_WINDOWS 4
+#endif
+
+namespace gpk {
+
+// fragment (block c, k-step ks = 4 I + s) in the windowed kernel's consumption order
+__host__ __device__ constexpr int hess_win_frag_index(int c, int I, int s, int nblk) {
+  return (4 * I + s) * nblk + c;
+}
+
+// Geometry: FOUR waves per workgroup (one per SIMD) and TWO workgroups per CU.  The two waves of a
+// SIMD then belong to different workgroups, whose barriers do not tie them together: while one is
+// in its latency-bound parts (item start, reductions, finish and stores: a quarter of an item in
+// lockstep) the other keeps the fp64 pipe busy.  80 KB of LDS per workgroup: the training rows at
+// their natural stride and two 32-fragment chunks.
+struct WGeo {
+  static constexpr int kWaves = 4;
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr int kWGPerCU = 2;
+  static constexpr int kRowsPerWG = kWaves * kTile;
+  static constexpr int kChunk = 32;
+};
+// LDS row stride of a training point [x'', alpha, h]: D + 2 reals rounded up to 16 bytes
+template <typename T> __host__ __device__ constexpr int win_row_stride(int D) {
+  return (D + 2 + (16 / (int)sizeof(T)) - 1) / (16 / (int)sizeof(T)) * (16 / (int)sizeof(T));
+}
+
+template <typename T, int D, int NB>
+__global__ __launch_bounds__(WGeo::kThreads, 2)
+void hessian_win_kernel(HessMfmaArgs<T> p) {
+  typedef Real<T> R;
+  typedef typename R::acc_t acc_t;
+  constexpr int kThreads = WGeo::kThreads;
+  constexpr int kWaves = WGeo::kWaves;
+  constexpr int kRowsPerWG = WGeo::kRowsPerWG;
+  constexpr int NP = 16 * NB;
+  constexpr int DS = win_row_stride<T>(D);          // LDS image
+  constexpr int DSG = row_stride(D);                // packed global image
+  constexpr int NB4 = hess_nb4(D);
+  constexpr int NBLK = hess_blocks(D);
+  constexpr int NKS = 4 * NB;                                   // k-steps
+  constexpr int NW = GP_HESS_WINDOWS < NKS ? GP_HESS_WINDOWS : NKS;
+  constexpr int KW = (NKS + NW - 1) / NW;                       // k-steps per window (the last may be short)
+  constexpr int NF = NKS * NBLK;
+  constexpr int kChunk = WGeo::kChunk;
+  constexpr int NCH = (NF + kChunk - 1) / kChunk;
+
+  __shared__ __attribute__((aligned(16))) T s_xa[NP * DS];
+  __shared__ __attribute__((aligned(16))) T s_fr[2][kChunk * 64];
+  __shared__ T s_sd[2 * D + 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ml = lane & 15;
+  const int g = lane >> 4;
+
+  for (int i = tid; i < NP * DS; i += kThreads) s_xa[i] = p.xa[(i / DS) * DSG + i % DS];
+  if (tid < 2 * D + 1) s_sd[tid] = (tid == 2 * D || (tid % D) < p.d_actual) ? p.sd[tid] : T(0);
+  __syncthreads();
+  const T b = s_sd[2 * D];
+
+  const long long n_groups = (p.M + kRowsPerWG - 1) / kRowsPerWG;
+#if GP_STAMPS   // diagnostic build (tools/hess_stamps.py): [0] item start, [1] phase A, [2] phase B, [3] reductions, [4] finish + stores
+  unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long seg_t0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_t0)::"memory");
+#endif
+  // the lane's raw test row, loaded one item ahead: at the end of the last window's phase A, when the
+  // registers of the training row are free again, so that the HBM latency of these loads is not the
+  // first thing an item waits for
+  T rraw[D];
+  auto load_row = [&](long long grp_) __attribute__((always_inline)) {
+    const long long m_ = grp_ * kRowsPerWG + wave * kTile + ml;
+    const long long mc_ = m_ < p.M ? m_ : p.M - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int dc = d < p.d_actual ? d : p.d_actual - 1;     // padded dims: sd = centre = 0
+      rraw[d] = p.testing[mc_ * p.d_actual + dc];
+    }
+  };
+  if ((long long)blockIdx.x < n_groups) load_row(blockIdx.x);
+  for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    __syncthreads();            // previous item's readers of s_fr[0] are done
+    stage_chunk<T, kWaves, kChunk>(p.pfrags, &s_fr[0][0], wave, lane);
+
+    T t[D];
+    T gm = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      t[d] = s_sd[d] * (rraw[d] - s_sd[D + d]);
+      gm = fma(t[d], t[d], gm);
+    }
+    gm *= T(-0.5);
+    T mu = T(0);
+    T ga[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ga[d] = T(0);
+    T kvw[KW];                  // the weights of the current window
+    acc_t accs[NBLK];
+#pragma unroll
+    for (int c = 0; c < NBLK; ++c) accs[c] = acc_t{T(0), T(0), T(0), T(0)};
+
+    // phase A of window q: its KW k-steps, one training point at a time (two waves per SIMD cover
+    // the latencies; there is no register for a second point in flight)
+    auto window_weights = [&](auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      static_for<KW>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int ks = q * KW + decltype(jc)::value;
+        if constexpr (ks < NKS) {
+          const int i = own_index<T>(ks >> 2, ks & 3, g);
+          const T* row = &s_xa[i * DS];
+          T x[D];
+#pragma unroll
+          for (int d = 0; d < D; ++d) x[d] = row[d];
+          const T al = row[D];
+          T k;
+          if constexpr (R::kExpand) {
+            k = row[D + 1] + gm;
+#pragma unroll
+            for (int d = 0; d < D; ++d) k = fma(x[d], t[d], k);
+            k = R::exp_(k);
+          } else {
+            T r2 = T(0);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              x[d] -= t[d];
+              r2 = fma(x[d], x[d], r2);
+            }
+            k = b * R::exp_(T(-0.5) * r2);
+          }
+          const T w = k * al;
+          kvw[ks - q * KW] = w;
+          mu += w;
+#pragma unroll
+          for (int d = 0; d < D; ++d) ga[d] = fma(w, x[d], ga[d]);
+        }
+      });
+    };
+
+    constexpr int kAhead = GP_AHEAD;
+    T afr[kAhead];
+    GP_STAMP(0);
+    window_weights(std::integral_constant<int, 0>{});
+    GP_STAMP(1);
+    static_for<NF>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      constexpr int ch = f / kChunk, fl = f % kChunk;
+      constexpr int ks = f / NBLK, c = f % NBLK;
+      constexpr int q = ks / KW;
+      if constexpr (c == 0 && ks % KW == 0 && q > 0) {
+        GP_STAMP(2);
+        window_weights(std::integral_constant<int, q>{});
+        if constexpr (q == (NKS - 1) / KW) load_row(grp + gridDim.x < n_groups ? grp + gridDim.x : grp);
+        GP_STAMP(1);
+      }
+      if constexpr (fl == 0) {
+        dma_wait();       // this wave's pieces of chunk ch have landed
+        __syncthreads();  // chunk ch visible; everyone finished reading chunk ch-1
+        if constexpr (ch + 1 < NCH)
+          stage_chunk<T, kWaves, kChunk>(p.pfrags + (ch + 1) * kChunk * 64, &s_fr[(ch + 1) & 1][0], wave, lane);
+        static_for<kAhead - 1>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (j < kChunk && f + j < NF) afr[j % kAhead] = s_fr[ch & 1][j * 64 + lane];
+        });
+      }
+      if constexpr (fl + kAhead - 1 < kChunk && f + kAhead - 1 < NF)
+        afr[(fl + kAhead - 1) % kAhead] = s_fr[ch & 1][(fl + kAhead - 1) * 64 + lane];
+      accs[c] = R::mfma(afr[fl % kAhead], kvw[ks - q * KW], accs[c]);
+    });
+
+    GP_STAMP(2);
+    // (everything only the finish needs is formed here, not carried through the windows: the
+    // registers are full there, and what does not fit goes to scratch and comes back slowly)
+    const T poison = gm - gm;   // NaN for rows holding a NaN or an infinity (exp_ clamps)
+    mu = xor_reduce_groups(mu) + poison;
+    static_for<(D + 5) / 6>([&](auto bc) {
+      constexpr int d0 = decltype(bc)::value * 6;
+      constexpr int nb_ = (D - d0 < 6) ? (D - d0) : 6;
+      xor_reduce_groups_n<T, nb_>(&ga[d0]);
+    });
+    // the epilogue needs t''_d, G_d for a compile-time d -- the lane's own registers, live through every
+    // window anyway -- and for d2 = 4 bj + g, picked out per lane group here
+    T tq[NB4], gq[NB4];
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) tq[j] = gq[j] = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if ((d & 3) == g) {
+        tq[d >> 2] = t[d];
+        gq[d >> 2] = ga[d];
+      }
+    GP_STAMP(3);
+    // ---------------- finish and store every block ----------------------------------------
+    T sdq[NB4];                 // sqrt(e) of this lane group's column in every block: d2 = 4 bj + g
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) sdq[j] = (4 * j + g < D) ? s_sd[4 * j + g] : T(0);
+    // the row length is made opaque once per item: the store offsets of the 10 blocks are then
+    // recomputed here with a few integer instructions instead of being hoisted out of the item loop
+    // into two dozen registers that the windows would push to scratch
+    int da = p.d_actual;
+    asm volatile("" : "+s"(da));
+    const long long m = grp * kRowsPerWG + wave * kTile + ml;
+    const bool row_ok = m < p.M;
+    T* out = p.hess + (row_ok ? m : p.M - 1) * (long long)da * da;
+    const bool vec_ok = (da % (16 / (int)sizeof(T)) == 0) && (((unsigned long long)p.hess & 15) == 0);
+    static_for<NBLK>([&](auto cbc) {
+      constexpr int cbv = decltype(cbc)::value;
+      constexpr int bi = hess_block_bi(cbv), bj = hess_block_bj(cbv);
+      const acc_t a = accs[cbv];
+      const int d2 = 4 * bj + g;
+      T v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 4 * bi + r;
+        v[r] = T(0);
+        if (d < D) {            // (compile time after unrolling)
+          const T td = t[d], gd = ga[d];
+          T x = a[r];
+          x = fma(-gd, tq[bj], x);
+          x = fma(-td, gq[bj], x);
+          x = fma(mu * td, tq[bj], x);
+          const T sdd = s_sd[d];
+          x *= sdd * sdq[bj];
+          if (bi == bj && r == g) x = fma(-(sdd * sdd), mu, x);
+          v[r] = x;
+        }
+      }
+      if (vec_ok) {
+        // 16-byte stores: the mirror image as it is, the block's own rows after a 4 x 4 transpose
+        // across the lane groups (see hessian_mfma_kernel)
+        T vt[4] = {v[0], v[1], v[2], v[3]};
+        transpose_groups4(vt);
+        if constexpr (bi != bj) {
+          if (row_ok && d2 < da) store_row4<T>(out + d2 * da + 4 * bi, v, da - 4 * bi);
+          if (row_ok && 4 * bi + g < da)
+            store_row4<T>(out + (4 * bi + g) * da + 4 * bj, vt, da - 4 * bj);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vt[r] = (r <= g) ? v[r] : vt[r];
+          if (row_ok && d2 < da) store_row4<T>(out + d2 * da + 4 * bi, vt, da - 4 * bi);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 4 * bi + r;
+          if (row_ok && d <= d2 && d2 < da) {
+            out[d * da + d2] = v[r];
+            if (d != d2) out[d2 * da + d] = v[r];
+          }
+        }
+      }
+    });
+    GP_STAMP(4);
+  }
+#if GP_STAMPS
+  if (lane == 0 && p.dbg) {
+    for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&p.dbg[k_], seg_sum[k_]);
+    atomicAdd(&p.dbg[7], 1ull);   // wave count
+  }
+#endif
+}
+
+}  // namespace gpk

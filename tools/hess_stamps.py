@@ -1,0 +1,39 @@
+"""Where does an item of hessian_win_kernel spend its cycles?  Needs a library built with
+-DGP_STAMPS=1 (GP_PREDICT_LIB=...): every wave sums the shader cycles of five segments of its
+items; shares are printed.  The stamped build's run time is never quoted.
+
+    python -m gp_emulator_amd.build --define GP_STAMPS=1 --lib gp_emulator_amd/libgp_predict_hip_stamps.so
+    GP_PREDICT_LIB=gp_emulator_amd/libgp_predict_hip_stamps.so python tools/hess_stamps.py
+"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gp_emulator_amd import _lib
+from bench import synthetic_inputs
+
+ctx = _lib.Context(0)
+N, D, M, WAVES = 300, 16, 1000000, 8
+inputs, testing, theta, invQ, invQt = synthetic_inputs(1, N, D, M)
+model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, np.float64)
+d_t = ctx.to_device(testing)
+d_h = ctx.malloc(M * D * D * 8)
+d_dbg = ctx.to_device(np.zeros(8, np.uint64))
+_lib.check(ctx.lib.gp_ctx_set_debug_buffer(ctx.h, d_dbg))
+for _ in range(2):
+    model.hessian_device(d_t, d_h, M)
+ctx.synchronize()
+ctx.h2d(d_dbg, np.zeros(8, np.uint64))
+K = 5
+for _ in range(K):
+    model.hessian_device(d_t, d_h, M)
+ctx.synchronize()
+s = ctx.to_host(d_dbg, (8,), np.uint64).astype(np.float64)
+waves = s[7] / K
+names = ["0 item start: barrier, DMA issue, test row", "1 phase A (all windows)", "2 phase B (matrix instructions, chunk barriers)",
+         "3 lane-group reductions, t / G to LDS", "4 finish + stores"]
+tot = s[:5].sum()
+items_per_wave = (M / (16 * WAVES)) / (waves / WAVES)
+print("N=%d D=%d: waves per launch %.0f, items per wave %.2f" % (N, D, waves, items_per_wave))
+for n, v in zip(names, s[:5]):
+    print("%-52s %5.1f %%   %8.0f cycles per item" % (n, 100 * v / tot, v / K / waves / items_per_wave))
+print("total cycles per item (per wave) %.0f" % (tot / K / waves / items_per_wave))
