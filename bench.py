@@ -579,8 +579,8 @@ def main():
         if hess_mfma:
             # the large fp64 instances run the windowed form (gp_hessian_win_kernel.hpp; hess_wide's rule)
             nb_, kd_ = minfo["kernel_nb"], minfo["kernel_d"]
-            win = (a.precision == "f64" and (nb_ >= 16 or (nb_ >= 12 and kd_ >= 16))
-                   and os.environ.get("GP_HESS_WIN", "1") != "0")
+            big = (nb_ >= 16 and (a.precision == "f64" or kd_ >= 11)) or (nb_ >= 12 and kd_ >= 16)
+            win = big and os.environ.get("GP_HESS_WIN", "1") != "0"
             kfull = "%s<%s,%d,%d>" % ("hessian_win_kernel" if win else "hessian_mfma_kernel", ctype, kd_, nb_)
         elif kind == "hessian":
             kfull = "hessian_kernel<%s,%d>" % (ctype, minfo["kernel_d"])

@@ -652,8 +652,8 @@ static int ensure_hess_frags(gp_ctx* ctx, gp_model* m) {
   const int kd = m->kernel_d, knb = m->kernel_nb, N = m->n_train;
   // geometry of hessian_mfma_kernel<T, kd, knb> (gpk::HGeo): wide instances take their
   // fragments in paired order and in chunks of one pair block
-  const bool wide = gpk::hess_wide<T>(kd, knb);
-  const bool win = wide && hess_use_win();      // windowed kernel: k-step-major fragments, standard chunks
+  const bool win = gpk::hess_win<T>(kd, knb) && hess_use_win();   // windowed kernel: k-step-major fragments, 32 per chunk
+  const bool wide = !win && gpk::hess_wide<T>(kd, knb);
   const int chunk = win ? gpk::WGeo::kChunk : wide ? 4 * knb : gpk::Geo<T>::kChunk;
   const int nblk = gpk::hess_blocks(kd);
   const size_t n = (size_t)gpk::hess_frag_count_padded(kd, knb, chunk) * 64;
@@ -700,12 +700,12 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
     h.hess = (T*)d_hess;
     h.M = M;
     h.d_actual = m->n_inputs;
-    const bool wide = gpk::hess_wide<T>(m->kernel_d, m->kernel_nb);
-    h.use_win = wide && hess_use_win() ? 1 : 0;
+    h.use_win = gpk::hess_win<T>(m->kernel_d, m->kernel_nb) && hess_use_win() ? 1 : 0;
+    const bool wide = !h.use_win && gpk::hess_wide<T>(m->kernel_d, m->kernel_nb);
     h.dbg = (unsigned long long*)ctx->dbg;
-    const int kRowsPerWG = wide ? 4 * gpk::kTile : gpk::Geo<T>::kRowsPerWG;      // wide and windowed: 4-wave workgroups
+    const int kRowsPerWG = (wide || h.use_win) ? 4 * gpk::kTile : gpk::Geo<T>::kRowsPerWG;   // 4-wave workgroups
     const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG;
-    int64_t grid = (int64_t)ctx->compute_units * (h.use_win ? gpk::WGeo::kWGPerCU : gpk::Geo<T>::kWGPerCU);
+    int64_t grid = (int64_t)ctx->compute_units * (h.use_win ? gpk::win_wg_per_cu<T>() : gpk::Geo<T>::kWGPerCU);
     if (grid > groups) grid = groups;
     hipError_t e = launch_hessm<T>(m->kernel_nb, m->kernel_d, h, (int)grid, stream);
     if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian kernel launch: %s", hipGetErrorString(e));

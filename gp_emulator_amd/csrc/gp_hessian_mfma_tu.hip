@@ -12,7 +12,7 @@ namespace gpk {
 
 template <int D>
 static hipError_t launch_one(const HessMfmaArgs<GP_T>& a, int grid, hipStream_t stream) {
-  if constexpr (hess_wide<GP_T>(D, GP_NB)) {
+  if constexpr (hess_win<GP_T>(D, GP_NB)) {
     if (a.use_win) {      // the windowed form (gp_hessian_win_kernel.hpp): k-step-major fragments, 4-wave workgroups
       hipLaunchKernelGGL((hessian_win_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(WGeo::kThreads), 0, stream, a);
       return hipGetLastError();

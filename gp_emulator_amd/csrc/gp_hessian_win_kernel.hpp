@@ -1,5 +1,5 @@
-// Hessian on the matrix core, WINDOWED form for the large fp64 instances (hess_wide: N > 240, or
-// N > 176 at D = 16).
+// Hessian on the matrix core, WINDOWED form for the large instances (hess_win: fp64 N > 240, or
+// N > 176 at D = 16; fp32 the same from D = 11 up).
 //
 // hessian_mfma_kernel walks the products block by block: one accumulator at a time runs over ALL
 // training points, so the whole weight tile of a wave's 16 rows must sit in registers through the
@@ -40,17 +40,27 @@ __host__ __device__ constexpr int hess_win_frag_index(int c, int I, int s, int n
 struct WGeo {
   static constexpr int kWaves = 4;
   static constexpr int kThreads = kWaves * 64;
-  static constexpr int kWGPerCU = 2;
   static constexpr int kRowsPerWG = kWaves * kTile;
   static constexpr int kChunk = 32;
 };
+// workgroups per CU = waves per SIMD (256 registers each; three for fp32 spilled 120 registers)
+template <typename T> __host__ __device__ constexpr int win_wg_per_cu() { return 2; }
+// Instances that run the windowed kernel: the ones whose weight tile crowds the block-major kernel
+// (fp64: hess_wide's rule).  In fp32 the block-major kernel has the registers (three waves per
+// SIMD) and wins at small D, where an item is short; measured on one box, N = 250 / 300
+// (tools/hessian_kernels.py): D = 8 0.49 vs 0.54 ms, D = 10 0.84 vs 0.88, D = 11 0.93 vs 0.91,
+// D = 12 1.12 vs 1.04, D = 16 1.71 vs 1.55 (block-major vs windowed).
+template <typename T> __host__ __device__ constexpr bool hess_win(int D, int NB) {
+  if (sizeof(T) == 8) return NB >= 16 || (NB >= 12 && D >= 16);
+  return (NB >= 16 && D >= 11) || (NB >= 12 && D >= 16);
+}
 // LDS row stride of a training point [x'', alpha, h]: D + 2 reals rounded up to 16 bytes
 template <typename T> __host__ __device__ constexpr int win_row_stride(int D) {
   return (D + 2 + (16 / (int)sizeof(T)) - 1) / (16 / (int)sizeof(T)) * (16 / (int)sizeof(T));
 }
 
 template <typename T, int D, int NB>
-__global__ __launch_bounds__(WGeo::kThreads, 2)
+__global__ __launch_bounds__(WGeo::kThreads, (win_wg_per_cu<T>()))
 void hessian_win_kernel(HessMfmaArgs<T> p) {
   typedef Real<T> R;
   typedef typename R::acc_t acc_t;
@@ -148,8 +158,8 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
             T r2 = T(0);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-              x[d] -= t[d];
-              r2 = fma(x[d], x[d], r2);
+              const T dl = x[d] - t[d];               // (x itself stays: G below is sum w x'')
+              r2 = fma(dl, dl, r2);
             }
             k = b * R::exp_(T(-0.5) * r2);
           }
