@@ -115,7 +115,10 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   };
   if ((long long)blockIdx.x < n_groups) load_row(blockIdx.x);
   for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    __syncthreads();            // previous item's readers of s_fr[0] are done
+    // chunk 0 goes to buffer 0.  With an even number of chunks per item the previous item's last chunk
+    // sat in buffer 1, and buffer 0's last readers (the chunk before it) passed a barrier since: no
+    // barrier here, the waves of the workgroup may run into the next item a finish apart
+    if constexpr (NCH % 2 == 1) __syncthreads();
     stage_chunk<T, kWaves, kChunk>(p.pfrags, &s_fr[0][0], wave, lane);
 
     T t[D];
