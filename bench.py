@@ -303,6 +303,8 @@ def executed_flop_per_point(N, D, kind, minfo, hess_mfma):
         phase_a = 3 * N * D + 3 * N + 2 * N + 2 * N * D
         if hess_mfma:
             nb4 = (kd + 3) // 4
+            if hess_mfma == "win":      # s and G_d ride on the matrix core's spare slots: not in phase A any more
+                phase_a -= 2 * N + 2 * N * D
             return nb4 * (nb4 + 1) // 2 * 4 * nb * 2048 // 16 + phase_a
         return 2 * 16 * ((N + 15) // 16) * kd * (kd + 1) // 2 + phase_a
     nk = minfo["kernel_nk"]
@@ -557,7 +559,12 @@ def main():
         hess_mfma = (kind == "hessian" and minfo["kernel_d"] in (8, 10, 11, 12, 16)
                      and minfo["kernel_nb"] > 0 and not int(os.environ.get("GP_HESS_VALU", "0")))
         flop_pt = flop_per_point(N, D, kind)
-        exec_flop_pt = executed_flop_per_point(N, D, kind, minfo, hess_mfma)
+        hess_win = False
+        if hess_mfma:       # the large instances run the windowed form (gp_hessian_win_kernel.hpp; hess_win's rule)
+            nb_, kd_ = minfo["kernel_nb"], minfo["kernel_d"]
+            big = (nb_ >= 16 and (a.precision == "f64" or kd_ >= 11)) or (nb_ >= 12 and kd_ >= 16)
+            hess_win = big and os.environ.get("GP_HESS_WIN", "1") != "0"
+        exec_flop_pt = executed_flop_per_point(N, D, kind, minfo, "win" if hess_win else hess_mfma)
         if kind == "hessian":
             byte_pt = (D + D * D) * isz
         else:
@@ -577,11 +584,8 @@ def main():
                 traffic = None
         ctype = "double" if a.precision == "f64" else "float"
         if hess_mfma:
-            # the large fp64 instances run the windowed form (gp_hessian_win_kernel.hpp; hess_wide's rule)
-            nb_, kd_ = minfo["kernel_nb"], minfo["kernel_d"]
-            big = (nb_ >= 16 and (a.precision == "f64" or kd_ >= 11)) or (nb_ >= 12 and kd_ >= 16)
-            win = big and os.environ.get("GP_HESS_WIN", "1") != "0"
-            kfull = "%s<%s,%d,%d>" % ("hessian_win_kernel" if win else "hessian_mfma_kernel", ctype, kd_, nb_)
+            kfull = "%s<%s,%d,%d>" % ("hessian_win_kernel" if hess_win else "hessian_mfma_kernel", ctype,
+                                      minfo["kernel_d"], minfo["kernel_nb"])
         elif kind == "hessian":
             kfull = "hessian_kernel<%s,%d>" % (ctype, minfo["kernel_d"])
         else:

@@ -668,7 +668,17 @@ static int ensure_hess_frags(gp_ctx* ctx, gp_model* m) {
           const int q = l & 15;             // MFMA output row = accumulator r of lane group g
           const int d = 4 * gpk::hess_block_bi(c) + gpk::hess_row_r<T>(q);
           const int d2 = 4 * gpk::hess_block_bj(c) + gpk::hess_row_g<T>(q);
-          if (gpk::slot_point<T>(i) >= N || d >= kd || d2 >= kd) continue;
+          if (gpk::slot_point<T>(i) >= N) continue;
+          if (win && gpk::hess_block_bi(c) == gpk::hess_block_bj(c)) {
+            // the windowed kernel takes G_n = sum w x''_n and s = sum w from the unused mirror slots of the
+            // diagonal blocks (gp_hessian_win_kernel.hpp, hess_gslot_*)
+            const int n = gpk::hess_gslot_of(gpk::hess_block_bi(c), gpk::hess_row_r<T>(q), gpk::hess_row_g<T>(q));
+            if (n >= 0) {
+              f[l] = n < kd ? (T)m->xs_host[(size_t)i * kd + n] : n == kd ? T(1) : T(0);
+              continue;
+            }
+          }
+          if (d >= kd || d2 >= kd) continue;
           f[l] = (T)(m->xs_host[(size_t)i * kd + d] * m->xs_host[(size_t)i * kd + d2]);
         }
       }

@@ -24,8 +24,27 @@
 #ifndef GP_HESS_WINDOWS
 #define GP_HESS_WINDOWS 4
 #endif
+#ifndef GP_HESS_WIN_GROUP
+#define GP_HESS_WIN_GROUP 2
+#endif
 
 namespace gpk {
+
+// G and s ride on the matrix core.  A diagonal 4 x 4 block computes every off-diagonal pair twice --
+// accumulator register r of lane group g is (4 bi + r, 4 bi + g), and only r <= g is used -- so its six
+// slots with r > g are free.  The windowed kernel's packed products put x''_n (n < D) and 1 (n == D)
+// there: slot n sits in diagonal block n / 6 at the (r, g) of hess_gslot_r / _g, and the accumulator comes
+// out as G_n = sum_i w_i x''_in, respectively s = sum_i w_i -- the 17 vector instructions per (training
+// point, test row) that accumulated them in phase A are gone (6 NB4 >= D + 1 for every compiled D).
+__host__ __device__ constexpr int hess_gslot_r(int n) { const int k = n % 6; return k == 0 ? 1 : k < 3 ? 2 : 3; }
+__host__ __device__ constexpr int hess_gslot_g(int n) { const int k = n % 6; return k == 0 ? 0 : k < 3 ? k - 1 : k - 3; }
+__host__ __device__ constexpr int hess_gslot_block(int n) { return hess_block_index(n / 6, n / 6); }
+// the slot that (diagonal block bi, register r, lane group g) carries, or -1
+__host__ __device__ constexpr int hess_gslot_of(int bi, int r, int g) {
+  if (r <= g) return -1;
+  const int k = r == 1 ? 0 : r == 2 ? 1 + g : 3 + g;
+  return 6 * bi + k;
+}
 
 // fragment (block c, k-step ks = 4 I + s) in the windowed kernel's consumption order
 __host__ __device__ constexpr int hess_win_frag_index(int c, int I, int s, int nblk) {
@@ -50,7 +69,11 @@ template <typename T> __host__ __device__ constexpr int win_wg_per_cu() { return
 // SIMD) and wins at small D, where an item is short; measured on one box, N = 250 / 300
 // (tools/hessian_kernels.py): D = 8 0.49 vs 0.54 ms, D = 10 0.84 vs 0.88, D = 11 0.93 vs 0.91,
 // D = 12 1.12 vs 1.04, D = 16 1.71 vs 1.55 (block-major vs windowed).
+#ifndef GP_HESS_WIN_ALL
+#define GP_HESS_WIN_ALL 0      // 1: every matrix-core instance (A/B builds)
+#endif
 template <typename T> __host__ __device__ constexpr bool hess_win(int D, int NB) {
+  if (GP_HESS_WIN_ALL) return true;
   if (sizeof(T) == 8) return NB >= 16 || (NB >= 12 && D >= 16);
   return (NB >= 16 && D >= 11) || (NB >= 12 && D >= 16);
 }
@@ -129,10 +152,6 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       gm = fma(t[d], t[d], gm);
     }
     gm *= T(-0.5);
-    T mu = T(0);
-    T ga[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) ga[d] = T(0);
     T kvw[KW];                  // the weights of the current window
     acc_t accs[NBLK];
 #pragma unroll
@@ -142,35 +161,48 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
     // the latencies; there is no register for a second point in flight)
     auto window_weights = [&](auto qc) __attribute__((always_inline)) {
       constexpr int q = decltype(qc)::value;
-      static_for<KW>([&](auto jc) __attribute__((always_inline)) {
-        constexpr int ks = q * KW + decltype(jc)::value;
-        if constexpr (ks < NKS) {
+      constexpr int GP = GP_HESS_WIN_GROUP;        // training points in flight (their serial chains interleave)
+      static_for<(KW + GP - 1) / GP>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j0 = decltype(jc)::value * GP;
+        T x[GP][D];
+        T al[GP], k[GP];
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+          const int ks = q * KW + j0 + u < NKS ? q * KW + j0 + u : NKS - 1;     // (a short tail repeats the last k-step)
           const int i = own_index<T>(ks >> 2, ks & 3, g);
           const T* row = &s_xa[i * DS];
-          T x[D];
 #pragma unroll
-          for (int d = 0; d < D; ++d) x[d] = row[d];
-          const T al = row[D];
-          T k;
-          if constexpr (R::kExpand) {
-            k = row[D + 1] + gm;
+          for (int d = 0; d < D; ++d) x[u][d] = row[d];
+          al[u] = row[D];
+          if constexpr (R::kExpand) k[u] = row[D + 1] + gm;
+        }
+        if constexpr (R::kExpand) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) k = fma(x[d], t[d], k);
-            k = R::exp_(k);
-          } else {
-            T r2 = T(0);
+          for (int d = 0; d < D; ++d) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-              const T dl = x[d] - t[d];               // (x itself stays: G below is sum w x'')
-              r2 = fma(dl, dl, r2);
-            }
-            k = b * R::exp_(T(-0.5) * r2);
+            for (int u = 0; u < GP; ++u) k[u] = fma(x[u][d], t[d], k[u]);
           }
-          const T w = k * al;
-          kvw[ks - q * KW] = w;
-          mu += w;
+        } else {
+          T r2[GP];
 #pragma unroll
-          for (int d = 0; d < D; ++d) ga[d] = fma(w, x[d], ga[d]);
+          for (int u = 0; u < GP; ++u) r2[u] = T(0);
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int u = 0; u < GP; ++u) {
+              const T dl = x[u][d] - t[d];
+              r2[u] = fma(dl, dl, r2[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < GP; ++u) k[u] = T(-0.5) * r2[u];
+        }
+        R::template exp_n<GP>(k);
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+          if constexpr (!R::kExpand) k[u] *= b;
+          // (s and G come out of the matrix phase: hess_gslot_*)
+          if (j0 + u < KW && q * KW + j0 + u < NKS) kvw[j0 + u] = k[u] * al[u];
         }
       });
     };
@@ -210,12 +242,16 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
     // (everything only the finish needs is formed here, not carried through the windows: the
     // registers are full there, and what does not fit goes to scratch and comes back slowly)
     const T poison = gm - gm;   // NaN for rows holding a NaN or an infinity (exp_ clamps)
-    mu = xor_reduce_groups(mu) + poison;
-    static_for<(D + 5) / 6>([&](auto bc) {
-      constexpr int d0 = decltype(bc)::value * 6;
-      constexpr int nb_ = (D - d0 < 6) ? (D - d0) : 6;
-      xor_reduce_groups_n<T, nb_>(&ga[d0]);
-    });
+    // s and G_d from their accumulator slots: the value sits in one lane group; zero elsewhere and the
+    // sum over the four groups (exact) hands it to all of them
+    auto slot_value = [&](auto nc) __attribute__((always_inline)) {
+      constexpr int n = decltype(nc)::value;
+      const T v = accs[hess_gslot_block(n)][hess_gslot_r(n)];
+      return xor_reduce_groups(g == hess_gslot_g(n) ? v : T(0));
+    };
+    const T mu = slot_value(std::integral_constant<int, D>{}) + poison;
+    T ga[D];
+    static_for<D>([&](auto dc) __attribute__((always_inline)) { ga[decltype(dc)::value] = slot_value(dc); });
     // the epilogue needs t''_d, G_d for a compile-time d -- the lane's own registers, live through every
     // window anyway -- and for d2 = 4 bj + g, picked out per lane group here
     T tq[NB4], gq[NB4];
