@@ -560,10 +560,8 @@ def main():
                      and minfo["kernel_nb"] > 0 and not int(os.environ.get("GP_HESS_VALU", "0")))
         flop_pt = flop_per_point(N, D, kind)
         hess_win = False
-        if hess_mfma:       # the large instances run the windowed form (gp_hessian_win_kernel.hpp; hess_win's rule)
-            nb_, kd_ = minfo["kernel_nb"], minfo["kernel_d"]
-            big = (nb_ >= 16 and (a.precision == "f64" or kd_ >= 11)) or (nb_ >= 12 and kd_ >= 16)
-            hess_win = big and os.environ.get("GP_HESS_WIN", "1") != "0"
+        if hess_mfma:       # the windowed form (gp_hessian_win_kernel.hpp) unless GP_HESS_WIN=0
+            hess_win = os.environ.get("GP_HESS_WIN", "1") != "0"
         exec_flop_pt = executed_flop_per_point(N, D, kind, minfo, "win" if hess_win else hess_mfma)
         if kind == "hessian":
             byte_pt = (D + D * D) * isz

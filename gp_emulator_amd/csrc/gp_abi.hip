@@ -626,9 +626,9 @@ hipError_t launch_hessm<double>(int knb, int kd, const gpk::HessMfmaArgs<double>
   return hipErrorInvalidValue;
 }
 
-// Large fp64 instances (hess_wide): the windowed kernel (gp_hessian_win_kernel.hpp) or, with
-// GP_HESS_WIN=0, the one-wave-per-SIMD geometry of hessian_mfma_kernel.  Read once: a model's packed
-// products follow the kernel that will read them.
+// The matrix-core Hessian runs the windowed kernel (gp_hessian_win_kernel.hpp) or, with GP_HESS_WIN=0,
+// the block-major hessian_mfma_kernel (A/B reference).  Read once: a model's packed products follow
+// the kernel that will read them.
 static bool hess_use_win() {
   static const bool v = [] { const char* ev = getenv("GP_HESS_WIN"); return !ev || atoi(ev) != 0; }();
   return v;
