@@ -172,4 +172,6 @@ if __name__ == "__main__":
         build(force=a.force, jobs=a.jobs, defines=["-D" + d for d in a.define], lib=a.lib)
     except RuntimeError as e:
         print(e, file=sys.stderr)
+        print("[gp build] FAILED (the library on disk, if any, is from an earlier build)", flush=True)   # last line of both streams
+        print("[gp build] FAILED", file=sys.stderr)
         sys.exit(1)

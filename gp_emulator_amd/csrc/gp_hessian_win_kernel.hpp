@@ -66,56 +66,9 @@ template <typename T> __host__ __device__ constexpr int win_wg_per_cu() { return
 // Instances that run the windowed kernel: all of them.  It started as the cure for the large fp64
 // instances (hess_wide), but with s and G on the matrix core and the decoupled workgroups it beats the
 // block-major kernel at every compiled shape in both precisions (profiles/r02_hessian_kernels.txt;
-// N = 120, D = 8: 0.52 vs 0.60 ms fp64).  hessian_mfma_kernel stays as the A/B reference (GP_HESS_WIN=0).
+// N = 120, D = 8: 0.49 vs 0.59 ms fp64).  hessian_mfma_kernel stays as the A/B reference (GP_HESS_WIN=0).
 template <typename T> __host__ __device__ constexpr bool hess_win(int, int) { return true; }
 
-// G and s ride on the matrix core.  A diagonal 4 x 4 block computes every off-diagonal pair twice --
-// accumulator register r of lane group g is (4 bi + r, 4 bi + g), and only r <= g is used -- so its six
-// slots with r > g are free.  The windowed kernel's packed products put x''_n (n < D) and 1 (n == D)
-// there: slot n sits in diagonal block n / 6 at the (r, g) of hess_gslot_r / _g, and the accumulator comes
-// out as G_n = sum_i w_i x''_in, respectively s = sum_i w_i -- the 17 vector instructions per (training
-// point, test row) that accumulated them in phase A are gone (6 NB4 >= D + 1 for every compiled D).
-__host__ __device__ constexpr int hess_gslot_r(int n) { const int k = n % 6; return k == 0 ? 1 : k < 3 ? 2 : 3; }
-__host__ __device__ constexpr int hess_gslot_g(int n) { const int k = n % 6; return k == 0 ? 0 : k < 3 ? k - 1 : k - 3; }
-__host__ __device__ constexpr int hess_gslot_block(int n) { return hess_block_index(n / 6, n / 6); }
-// the slot that (diagonal block bi, register r, lane group g) carries, or -1
-__host__ __device__ constexpr int hess_gslot_of(int bi, int r, int g) {
-  if (r <= g) return -1;
-  const int k = r == 1 ? 0 : r == 2 ? 1 + g : 3 + g;
-  return 6 * bi + k;
-}
-
-// fragment (block c, k-step ks = 4 I + s) in the windowed kernel's consumption order
-__host__ __device__ constexpr int hess_win_frag_index(int c, int I, int s, int nblk) {
-  return (4 * I + s) * nblk + c;
-}
-
-// Geometry: FOUR waves per workgroup (one per SIMD) and TWO workgroups per CU.  The two waves of a
-// SIMD then belong to different workgroups, whose barriers do not tie them together: while one is
-// in its latency-bound parts (item start, reductions, finish and stores: a quarter of an item in
-// lockstep) the other keeps the fp64 pipe busy.  80 KB of LDS per workgroup: the training rows at
-// their natural stride and two 32-fragment chunks.
-struct WGeo {
-  static constexpr int kWaves = 4;
-  static constexpr int kThreads = kWaves * 64;
-  static constexpr int kRowsPerWG = kWaves * kTile;
-  static constexpr int kChunk = 32;
-};
-// workgroups per CU = waves per SIMD (256 registers each; three for fp32 spilled 120 registers)
-template <typename T> __host__ __device__ constexpr int win_wg_per_cu() { return 2; }
-// Instances that run the windowed kernel: the ones whose weight tile crowds the block-major kernel
-// (fp64: hess_wide's rule).  In fp32 the block-major kernel has the registers (three waves per
-// SIMD) and wins at small D, where an item is short; measured on one box, N = 250 / 300
-// (tools/hessian_kernels.py): D = 8 0.49 vs 0.54 ms, D = 10 0.84 vs 0.88, D = 11 0.93 vs 0.91,
-// D = 12 1.12 vs 1.04, D = 16 1.71 vs 1.55 (block-major vs windowed).
-#ifndef GP_HESS_WIN_ALL
-#define GP_HESS_WIN_ALL 0      // 1: every matrix-core instance (A/B builds)
-#endif
-template <typename T> __host__ __device__ constexpr bool hess_win(int D, int NB) {
-  if (GP_HESS_WIN_ALL) return true;
-  if (sizeof(T) == 8) return NB >= 16 || (NB >= 12 && D >= 16);
-  return (NB >= 16 && D >= 11) || (NB >= 12 && D >= 16);
-}
 // LDS row stride of a training point [x'', alpha, h]: D + 2 reals rounded up to 16 bytes
 template <typename T> __host__ __device__ constexpr int win_row_stride(int D) {
   return (D + 2 + (16 / (int)sizeof(T)) - 1) / (16 / (int)sizeof(T)) * (16 / (int)sizeof(T));
