@@ -31,6 +31,16 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.gp_version_string()
 
 
+def test_library_on_disk_is_built_from_these_sources():
+    """The in-tree .so travels to the GPU box as it is: it must be the build of the sources beside it
+    (build.py stamps the library with a digest of csrc/, include/ and the flags)."""
+    from gp_emulator_amd import build as gpbuild
+    stamp = gpbuild.LIB + ".digest"
+    assert os.path.exists(gpbuild.LIB) and os.path.exists(stamp), "run python -m gp_emulator_amd.build"
+    assert open(stamp).read().strip() == gpbuild.source_digest() + "" + "None", \
+        "libgp_predict_hip.so is stale (sources changed, or the last build failed): python -m gp_emulator_amd.build"
+
+
 def test_header_is_plain_c_and_links_from_c(tmp_path):
     """The boundary is a C ABI: include/gp_predict_hip.h compiles as strict C99 and a C program
     links against the library and calls it (device count, error string, version) -- no C++, no
