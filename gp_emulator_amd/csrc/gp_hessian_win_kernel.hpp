@@ -10,13 +10,19 @@
 //
 // Here the ORDER is turned round instead.  The training points are taken in windows of KW k-steps
 // (4 KW points per lane group); for each window
-//   phase A   the weights of the window only (2 KW registers), s and G accumulated as before;
+//   phase A   the weights of the window only (2 KW registers), two training points in flight;
 //   phase B   for every k-step of the window, one matrix instruction into EACH of the NBLK block
 //             accumulators (fragments packed k-step-major: (k-step, block)) -- NBLK independent
 //             chains, no dependent issue at all.
 // All NBLK accumulators stay live (8 NBLK registers: 80 at D = 16), but the weight tile never
-// exists as a whole: 80 + 2 KW + t'' + G + a training row fit 256 registers, so the kernel runs
-// two waves per SIMD without spills.  The blocks are finished and stored after the last window.
+// exists as a whole: 80 + 2 KW + t'' + two training rows fit 256 registers, so the kernel runs two
+// waves per SIMD without spills.  s and G_d are not accumulated in phase A at all: they come out of
+// spare accumulator slots of the diagonal blocks (hess_gslot_*).  The blocks are finished and stored
+// after the last window.  Workgroups are four waves (one per SIMD), two per CU (WGeo): the two waves
+// of a SIMD belong to different workgroups and drift apart, so one's latency-bound parts (item start,
+// finish, stores) run under the other's pipe work.  Measured (profiles/r02_hessian_wide.txt,
+// r02_hessian_kernels.txt): config 5 (N = 300, D = 16) 2.25-2.31 ms in fp64 against 2.67-2.9 ms for the
+// wide geometry, 1.30 against 1.52-1.76 ms in fp32, and faster or equal at every other compiled shape.
 #pragma once
 #include "gp_hessian_mfma_kernel.hpp"
 
