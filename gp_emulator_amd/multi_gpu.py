@@ -50,6 +50,31 @@ def _device_context(device):
         return hit
 
 
+_shard_models = {}      # (device, id(gp), dtype) -> (fingerprint, Model); used under the device's lock
+
+
+def _shard_model(ctx, device, gp, precision):
+    """The emulator packed and uploaded on ``device``, kept between predict_sharded calls (a call per
+    time step of an assimilation re-sends the same emulator).  Re-made when the emulator's arrays
+    are replaced or theta / invQt change; at most eight emulators stay resident per device."""
+    from . import _lib
+    key = (device, id(gp), np.dtype(precision).str)
+    fp = (id(gp.inputs), id(gp.invQ), np.asarray(gp.theta).tobytes(), np.asarray(gp.invQt).tobytes())
+    hit = _shard_models.get(key)
+    if hit is not None and hit[0] == fp:
+        return hit[1]
+    if hit is not None:
+        hit[1].close()
+        del _shard_models[key]
+    mine = [k for k in _shard_models if k[0] == device]
+    while len(mine) >= 8:
+        _shard_models.pop(mine[0])[1].close()
+        mine.pop(0)
+    model = _lib.Model(ctx, np.exp(gp.theta), gp.inputs, gp.invQt, gp.invQ, precision)
+    _shard_models[key] = (fp, model)
+    return model
+
+
 def predict_sharded(gp, testing, devices, precision=np.float64, predict_fn=None, out=None):
     """mean, variance, gradient of ``gp`` at ``testing`` with rows sharded over ``devices``.
 
@@ -69,17 +94,13 @@ def predict_sharded(gp, testing, devices, precision=np.float64, predict_fn=None,
     errors = []
 
     def hip_shard(device, s, e):
-        from . import _lib
         ctx, lock = _device_context(device)
         with lock:
-            model = _lib.Model(ctx, np.exp(gp.theta), gp.inputs, gp.invQt, gp.invQ, precision)
-            try:
-                rows = testing[s:e]
-                if rows.dtype != np.float64:
-                    rows = rows.astype(np.float64)
-                model.predict(rows, out=(mu[s:e], var[s:e], deriv[s:e]))
-            finally:
-                model.close()
+            model = _shard_model(ctx, device, gp, precision)
+            rows = testing[s:e]
+            if rows.dtype != np.float64:
+                rows = rows.astype(np.float64)
+            model.predict(rows, out=(mu[s:e], var[s:e], deriv[s:e]))
 
     def work(device, s, e):
         try:
