@@ -47,5 +47,27 @@ for case in range(n_cases):
             e = err(href, gp.hessian(testing[:mh], is_gpu=True, precision=prec))
             worst[key] = max(worst[key], e)
             assert e <= tol, ("hessian", case, N, D, mh, prec, e)
+# batched emulators on shared inputs (perband.predict_bands; both kernel forms, emulator shards on one device)
+from gp_emulator_amd import perband  # noqa: E402
+n_batched = max(1, n_cases // 5)
+worst_b = 0.0
+for case in range(n_batched):
+    N, D = int(rs.randint(1, 321)), int(rs.randint(1, 17))
+    E, M = int(rs.randint(2, 10)), int(rs.choice([1, 16, 17, 100, 777, 3000]))
+    inputs, testing = rs.random_sample((N, D)), rs.random_sample((M, D))
+    gps = []
+    for e in range(E):
+        gp = GaussianProcess(inputs, [])
+        gp.theta, gp.invQ, gp.invQt = rs.random_sample(D + 2), rs.random_sample((N, N)), rs.random_sample(N)
+        gps.append(gp)
+    os.environ["GP_NO_FEW"] = str(case % 2)
+    devs = None if case % 3 else [0] * int(rs.randint(1, 4))
+    got = perband.predict_bands(gps, testing, devices=devs)
+    for e, gp in enumerate(gps):
+        ref = gp.predict(testing)
+        err_e = max(err(r, g[e]) for r, g in zip(ref, got))
+        worst_b = max(worst_b, err_e)
+        assert err_e <= 1e-10, ("batched", case, N, D, E, M, e, err_e)
+print("batched OK: %d cases, worst error %.2e" % (n_batched, worst_b))
 print("fuzz OK: %d cases; worst errors predict fp64 %.2e fp32 %.2e, Hessian fp64 %.2e fp32 %.2e" % (
     n_cases, worst["f64"], worst["f32"], worst["h64"], worst["h32"]))
