@@ -906,13 +906,14 @@ static int64_t slab_rows(const gp_ctx* ctx, const gp_model* m, int64_t M, int64_
   constexpr int64_t kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
   static const int rounds = [] { const char* ev = getenv("GP_HOST_SLAB_ROUNDS"); const int v = ev ? atoi(ev) : 2; return v < 1 ? 1 : v; }();
   int64_t slab = rounds * (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU * kRowsPerWG;
-  const int64_t by_bytes = ((int64_t)16 << 20) / (int64_t)(out_row_elems * sizeof(T));
+  // (batched emulators: 64 MiB of results per slab, so that a slab is a few hundred rows and an
+  // emulator's share of it a copy of kilobytes, not of bytes)
+  const int64_t by_bytes = ((int64_t)(m->n_emulators > 1 ? 64 : 16) << 20) / (int64_t)(out_row_elems * sizeof(T));
   if (slab > by_bytes) slab = by_bytes;
   if (M < 4 * slab && M >= 4 * 8192) slab = (M + 3) / 4;
   slab = (slab + kRowsPerWG - 1) / kRowsPerWG * kRowsPerWG;
   if (max_rows > 0 && slab > max_rows) slab = max_rows;
   if (slab > M) slab = M;
-  (void)m;
   return slab < 1 ? 1 : slab;
 }
 
@@ -1080,7 +1081,17 @@ static int predict_host(gp_ctx* ctx, const gp_model* m, const TH* testing, TH* r
   };
   // staged slab: mu [E][n], var [E][n], deriv [E][n*D] or [E][D][n]
   auto copy_out = [=](const T* o, int64_t s0, int64_t n, int64_t lo, int64_t hi) {
-    for (int e = 0; e < E; ++e) {
+    // a task is a share [lo, hi) of the slab's rows -- or, for batched emulators, the same share of
+    // the EMULATORS with all the slab's rows: every emulator's results are a separate run of the
+    // caller's arrays, and a row share of each would be a few dozen bytes per copy
+    int e_lo = 0, e_hi = E;
+    if (E > 1) {
+      e_lo = (int)((int64_t)E * lo / n);
+      e_hi = (int)((int64_t)E * hi / n);
+      lo = 0;
+      hi = n;
+    }
+    for (int e = e_lo; e < e_hi; ++e) {
       convert_range(result + (size_t)e * M + s0, o + (size_t)e * n, (size_t)lo, (size_t)hi);
       convert_range(error + (size_t)e * M + s0, o + (size_t)(E + e) * n, (size_t)lo, (size_t)hi);
       const T* od = o + (size_t)2 * E * n + (size_t)e * n * D;
