@@ -61,6 +61,7 @@ SIGNATURES = {
     "gp_hessian_f64": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_hessian_f32": (c_int, [c_void_p] + [c_void_p] * 5 + [c_i64, c_int, c_int, c_int]),
     "gp_reconstruct_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int]),
+    "gp_hessian_host_h64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
     "gp_mv_predict_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "gp_frag_index": (c_int, [c_int, c_int, c_int, c_int]),
     "gp_likelihood_batch_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -418,17 +419,22 @@ class Model:
                                              int(n_predict)), "gp_hessian_device")
 
     def hessian(self, testing, out=None):
-        """(M, D, D) Hessian of the mean for host rows, through the slab pipeline."""
-        testing = np.ascontiguousarray(testing, dtype=self.dtype)
+        """(M, D, D) Hessian of the mean for host rows, through the slab pipeline.  Rows of the
+        model's dtype give matrices of that dtype; float64 rows on a float32 model are converted
+        while they are staged and the matrices come back as float64 (``gp_hessian_host_h64``)."""
+        testing = np.asarray(testing)
+        h64 = testing.dtype == np.float64 and self.dtype != np.float64
+        hdt = np.dtype(np.float64) if h64 else self.dtype
+        testing = np.ascontiguousarray(testing, dtype=hdt)
         M, D = testing.shape
         if D != self.n_inputs:
             raise ValueError("testing has %d columns, model has %d inputs" % (D, self.n_inputs))
-        hess = self.ctx.out_pool.take((M, D, D), self.dtype) if out is None else out
-        if hess.shape != (M, D, D) or hess.dtype != self.dtype or not hess.flags["C_CONTIGUOUS"]:
-            raise ValueError("out must be a C-contiguous (M, D, D) array of the model's dtype")
+        hess = self.ctx.out_pool.take((M, D, D), hdt) if out is None else out
+        if hess.shape != (M, D, D) or hess.dtype != hdt or not hess.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous (M, D, D) %s array" % hdt)
         if M:
-            check(self.ctx.lib.gp_hessian_host(self.ctx.h, self.h, _ptr(testing), _ptr(hess), M),
-                  "gp_hessian_host")
+            fn = self.ctx.lib.gp_hessian_host_h64 if h64 else self.ctx.lib.gp_hessian_host
+            check(fn(self.ctx.h, self.h, _ptr(testing), _ptr(hess), M), "gp_hessian_host")
         return hess
 
     def close(self):

@@ -1108,13 +1108,13 @@ static int predict_host(gp_ctx* ctx, const gp_model* m, const TH* testing, TH* r
 }
 
 // Hessian for host arrays: (M, D, D) out, same pipeline (2 KiB per row of output at D = 16).
-template <typename T>
-static int hessian_host_model(gp_ctx* ctx, const gp_model* m, const T* testing, T* hess, int64_t M) {
+template <typename T, typename TH = T>
+static int hessian_host_model(gp_ctx* ctx, const gp_model* m, const TH* testing, TH* hess, int64_t M) {
   const int D = m->n_inputs;
   if (M == 0) return GP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t out_row = (size_t)D * D;
-  if ((size_t)M * out_row * sizeof(T) <= ((size_t)8 << 20)) {      // small call: direct copies (see predict_host)
+  if (sizeof(T) == sizeof(TH) && (size_t)M * out_row * sizeof(T) <= ((size_t)8 << 20)) {      // small call: direct copies (see predict_host)
     const size_t n_in = (size_t)M * D, n_out = (size_t)M * out_row;
     int rc = ensure_scratch(ctx, (n_in + n_out) * sizeof(T));
     if (rc) return rc;
@@ -1405,6 +1405,19 @@ int gp_hessian_host(gp_ctx* ctx, const gp_model* model, const void* testing, voi
     return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
   if (model->dtype == GP_F64) return guarded([&] { return hessian_host_model<double>(ctx, model, (const double*)testing, (double*)hess, n_predict); });
   return guarded([&] { return hessian_host_model<float>(ctx, model, (const float*)testing, (float*)hess, n_predict); });
+}
+
+int gp_hessian_host_h64(gp_ctx* ctx, const gp_model* model, const double* testing, double* hess, int64_t n_predict) {
+  if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
+  if (n_predict < 0) return fail(GP_ERR_INVALID, "n_predict < 0");
+  if (n_predict == 0) return GP_OK;
+  if (!testing || !hess) return fail(GP_ERR_INVALID, "null pointer");
+  if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  if (model->n_emulators != 1) return fail(GP_ERR_INVALID, "hessian is per emulator: batch of %d given", model->n_emulators);
+  if (model->n_inputs > GP_MAX_KERNEL_D)
+    return fail(GP_ERR_UNSUPPORTED, "hessian kernels are compiled for n_inputs <= %d", GP_MAX_KERNEL_D);
+  if (model->dtype == GP_F64) return guarded([&] { return hessian_host_model<double>(ctx, model, testing, hess, n_predict); });
+  return guarded([&] { return hessian_host_model<float, double>(ctx, model, testing, hess, n_predict); });
 }
 
 int gp_device_numa_node(int device, int* node) {

@@ -190,6 +190,11 @@ int gp_hessian_device(gp_ctx* ctx, const gp_model* model, const void* d_testing,
 /* host arrays of the model's dtype in and out, through the same slab pipeline as gp_predict_host */
 int gp_hessian_host(gp_ctx* ctx, const gp_model* model, const void* testing, void* hess,
                     int64_t n_predict);
+/* the same for float64 host arrays whatever the model's dtype: a float32 model takes the rows and
+ * returns the matrices through the staging copies' conversions (what hessian(precision=float32)
+ * means for a float64 caller; numpy casts of the (M, D, D) result cost more than the kernel) */
+int gp_hessian_host_h64(gp_ctx* ctx, const gp_model* model, const double* testing, double* hess,
+                        int64_t n_predict);
 int gp_hessian_f64(gp_ctx* ctx, const double* expX, const double* inputs, const double* invQt,
                    const double* testing, double* hess,
                    int64_t n_predict, int n_train, int n_inputs, int theta_size);
