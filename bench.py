@@ -445,10 +445,77 @@ def bench_strong(a, grp):
     return outd
 
 
+def launch_ranks(n_ranks):
+    """``python bench.py --gpus N`` with N > 1 and no launcher: start N child ranks of this same
+    command line, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run
+    sets them), and exit with their status.  This process makes no GPU call before or after the
+    children start (they are ordinary child processes, never an exec of a process that has touched
+    the GPU); rank 0's JSON line reaches stdout through the inherited pipe.  A rank that fails
+    takes the others down with it, so the job never hangs in a barrier and never reports fewer
+    GPUs than were asked for."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:          # the exact children started above, nothing else
+                    other.terminate()
+    if rc:
+        sys.stderr.write("bench.py: a rank of the %d-rank job failed (exit %d)\n" % (n_ranks, rc))
+    sys.exit(rc)
+
+
+def dry_run(a, grp):
+    """GP_BENCH_DRY_RUN=1 (tests/test_multi_gpu_cpu.py only): the rank plumbing of a --gpus N run
+    without any device work -- rendezvous, barrier, max-reduce, rank 0's line.  The line says so
+    (``data``), carries no rate and is never a measurement."""
+    def step():
+        time.sleep(0.001 * (1 + grp.rank))
+    from gp_emulator_amd import multi_gpu
+    dt = multi_gpu.timed_steps(grp, step, lambda: None, a.steps, a.warmup)
+    ranks = grp.sum(1)
+    if grp.rank == 0:
+        print(json.dumps({"metric": "dry run: rank plumbing only", "value": 0.0, "unit": "test-points/s",
+                          "n_gpus": grp.world, "ranks_seen": int(ranks), "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+                          "scaling": a.scaling, "vs_baseline": None, "dtype": a.precision,
+                          "data": "dry run (GP_BENCH_DRY_RUN=1): no device work, not a measurement",
+                          "config": {"workload": a.workload}}), flush=True)
+    grp.close()
+
+
 def main():
     a = parse()
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker)
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    launched = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and launched == 1 and "RANK" not in os.environ:
+        if a.workload in ("mv", "train"):
+            raise SystemExit("--workload %s is a one-GPU workload (--gpus 1)" % a.workload)
+        return launch_ranks(a.gpus)       # before anything here has touched the GPU
+    if launched != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line would report a GPU count that was not asked for"
+                         % (a.gpus, launched))
     if a.workload == "mv":
         return bench_reconstruct(a)
     if a.workload == "train":
@@ -457,8 +524,16 @@ def main():
 
     grp = multi_gpu.RankGroup()
     rank, world = grp.rank, grp.world
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if os.environ.get("GP_BENCH_DRY_RUN") == "1":
+        return dry_run(a, grp)
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
+    share = os.environ.get("GP_BENCH_SHARE_GPU") == "1"      # rehearsals: several ranks on one device, labelled
+    if world > ndev and not share:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible (GP_BENCH_SHARE_GPU=1 lets ranks share "
+                         "a device for a rehearsal; the line then reports the devices really used)" % (world, ndev))
+    n_gpus_used = min(world, ndev)
     if a.scaling == "strong":
         if a.workload != "c4":
             raise SystemExit("--scaling strong is the c4 workload's mode")

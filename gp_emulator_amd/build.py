@@ -83,23 +83,26 @@ def run(cmd):
     return r.stdout
 
 
-def build(force=False, jobs=None, verbose=True, defines=(), lib=None, only_nb=None):
+def build(force=False, jobs=None, verbose=True, defines=(), lib=None, only_units=None):
     """Compile and link.  ``defines`` (e.g. ["-DGP_WAVES=4"]), ``lib`` (output path) and
-    ``only_nb`` (restrict the kernel set) exist for tools/ab_bench.py variants only."""
+    ``only_units`` exist for tools/ab_bench.py variants only: a variant build compiles into its own
+    object directory; with ``only_units`` (object base names, e.g. ["hessm_f64_19"]) just those
+    units are compiled with the defines and every other object is taken from the main build."""
     global OBJ, LIB
-    variant = bool(defines or lib or only_nb)
+    variant = bool(defines or lib or only_units)
     obj_dir, lib_path = OBJ, LIB
     if variant:
-        tag = hashlib.sha256((" ".join(defines) + str(only_nb)).encode()).hexdigest()[:10]
+        tag = hashlib.sha256((" ".join(defines) + str(only_units)).encode()).hexdigest()[:10]
         obj_dir = os.path.join(CSRC, "_obj", "variant_" + tag)
         lib_path = lib or os.path.join(HERE, "libgp_predict_hip_%s.so" % tag)
-    return _build(force, jobs, verbose, list(defines), obj_dir, lib_path, only_nb)
+    return _build(force, jobs, verbose, list(defines), obj_dir, lib_path, only_units)
 
 
-def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
+def _build(force, jobs, verbose, defines, OBJ, LIB, only_units):
+    main_obj = os.path.join(CSRC, "_obj")
     os.makedirs(OBJ, exist_ok=True)
     stamp = LIB + ".digest"      # travels with the .so (the object dir does not)
-    digest = source_digest() + " ".join(defines) + str(only_nb)
+    digest = source_digest() + " ".join(defines) + str(only_units)
     if (not force and os.path.exists(LIB) and os.path.exists(stamp)
             and open(stamp).read().strip() == digest):
         if verbose:
@@ -146,13 +149,20 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_nb):
                 return 4 * int(a[8:])
         return 0
     tasks.sort(key=lambda c: -weight(c))
+    objs = [c[-1] for c in tasks]
+    if only_units:      # variant: the named units only; the rest comes from the main build's objects
+        keep = lambda o: os.path.basename(o)[:-2] in only_units
+        objs = [o if keep(o) else os.path.join(main_obj, os.path.basename(o)) for o in objs]
+        tasks = [c for c in tasks if keep(c[-1])]
+        missing = [o for o in objs if not keep(o) and not os.path.exists(o)]
+        if missing:
+            raise RuntimeError("variant build needs the main build's objects first: " + missing[0])
     if verbose:
         print("[gp build] compiling %d translation units with %d jobs" % (len(tasks), jobs))
     with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
         for out in ex.map(run, tasks):
             if out.strip() and verbose:
                 print(out)
-    objs = [c[-1] for c in tasks]
     run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     with open(stamp, "w") as fh:
         fh.write(digest)
@@ -167,9 +177,12 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--define", action="append", default=[], help="extra -D flag (variant build)")
     ap.add_argument("--lib", default=None, help="output path (variant build)")
+    ap.add_argument("--only", action="append", default=[],
+                    help="variant build: compile only this unit (object base name, e.g. hessm_f64_19); "
+                         "the other objects come from the main build")
     a = ap.parse_args()
     try:
-        build(force=a.force, jobs=a.jobs, defines=["-D" + d for d in a.define], lib=a.lib)
+        build(force=a.force, jobs=a.jobs, defines=["-D" + d for d in a.define], lib=a.lib, only_units=a.only or None)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         print("[gp build] FAILED (the library on disk, if any, is from an earlier build)", flush=True)   # last line of both streams

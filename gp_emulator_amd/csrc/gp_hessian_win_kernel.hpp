@@ -32,6 +32,11 @@
 #ifndef GP_HESS_WIN_GROUP
 #define GP_HESS_WIN_GROUP 2
 #endif
+// Timing-only ablations for tools/ab_bench.py (outputs are wrong when set), a bit mask:
+// 1 no chunk barriers in the matrix phase, 2 no stores, 4 no finish at all, 8 fragments staged once per item only
+#ifndef GP_HESS_ABL
+#define GP_HESS_ABL 0
+#endif
 
 namespace gpk {
 
@@ -222,9 +227,11 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
         GP_STAMP(1);
       }
       if constexpr (fl == 0) {
+        GP_STAMP(2);
         dma_wait();       // this wave's pieces of chunk ch have landed
-        __syncthreads();  // chunk ch visible; everyone finished reading chunk ch-1
-        if constexpr (ch + 1 < NCH)
+        if constexpr (!(GP_HESS_ABL & 1)) __syncthreads();  // chunk ch visible; everyone finished reading chunk ch-1
+        GP_STAMP(5);
+        if constexpr (ch + 1 < NCH && !(GP_HESS_ABL & 8))
           stage_chunk<T, kWaves, kChunk>(p.pfrags + (ch + 1) * kChunk * 64, &s_fr[(ch + 1) & 1][0], wave, lane);
         static_for<kAhead - 1>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
@@ -235,6 +242,15 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
         afr[(fl + kAhead - 1) % kAhead] = s_fr[ch & 1][(fl + kAhead - 1) * 64 + lane];
       accs[c] = R::mfma(afr[fl % kAhead], kvw[ks - q * KW], accs[c]);
     });
+#if GP_HESS_ABL & 4
+    {
+      T sum_ = gm;
+#pragma unroll
+      for (int c = 0; c < NBLK; ++c) sum_ += accs[c][0] + accs[c][1] + accs[c][2] + accs[c][3];
+      if (sum_ == T(-12345.678)) p.hess[0] = sum_;
+      continue;
+    }
+#endif
 
     GP_STAMP(2);
     // (everything only the finish needs is formed here, not carried through the windows: the
@@ -297,7 +313,13 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
           v[r] = x;
         }
       }
-      if (vec_ok) {
+#if GP_HESS_ABL & 2
+      if (v[0] + v[1] + v[2] + v[3] == T(-12345.678)) out[0] = v[0];
+      if (vec_ok && v[0] == T(-12345.678) && v[1] == T(-1.5))
+#else
+      if (vec_ok)
+#endif
+      {
         // 16-byte stores: the mirror image as it is, the block's own rows after a 4 x 4 transpose
         // across the lane groups (see hessian_mfma_kernel)
         T vt[4] = {v[0], v[1], v[2], v[3]};
@@ -311,7 +333,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
           for (int r = 0; r < 4; ++r) vt[r] = (r <= g) ? v[r] : vt[r];
           if (row_ok && d2 < da) store_row4<T>(out + d2 * da + 4 * bi, vt, da - 4 * bi);
         }
-      } else {
+      } else if (!(GP_HESS_ABL & 2)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int d = 4 * bi + r;
