@@ -2,6 +2,7 @@
 // dimensions where the matrix-core form beats (or ties with) the VALU one (D >= 8;
 // profiles/r01_hessian_kernels.txt).  Compiled by build.py with
 // -DGP_T=<float|double> -DGP_TNAME=<f32|f64> -DGP_NB=<blocks of 16 training points>.
+#include <stdlib.h>
 #include "gp_hessian_mfma_kernel.hpp"
 #include "gp_hessian_win_kernel.hpp"
 
@@ -10,11 +11,26 @@
 
 namespace gpk {
 
+// GP_HESS_DIRECT=1 (read once): the direct stores of round 2 for every call, the A/B reference of the
+// whole-line finish
+static bool hess_win_direct_stores() {
+  static const bool v = [] { const char* ev = getenv("GP_HESS_DIRECT"); return ev && atoi(ev) != 0; }();
+  return v;
+}
+
 template <int D>
 static hipError_t launch_one(const HessMfmaArgs<GP_T>& a, int grid, hipStream_t stream) {
   if constexpr (hess_win<GP_T>(D, GP_NB)) {
     if (a.use_win) {      // the windowed form (gp_hessian_win_kernel.hpp): k-step-major fragments, 4-wave workgroups
-      hipLaunchKernelGGL((hessian_win_kernel<GP_T, D, GP_NB>), dim3(grid), dim3(WGeo::kThreads), 0, stream, a);
+      if constexpr (win_lds_out<GP_T>(D)) {
+        // whole-line stores through LDS when the caller's rows are exactly D long and the matrix is aligned
+        if (a.d_actual == D && (((unsigned long long)a.hess | (unsigned long long)a.testing) & 15) == 0 &&
+            !hess_win_direct_stores()) {
+          hipLaunchKernelGGL((hessian_win_kernel<GP_T, D, GP_NB, true>), dim3(grid), dim3(WGeo::kThreads), 0, stream, a);
+          return hipGetLastError();
+        }
+      }
+      hipLaunchKernelGGL((hessian_win_kernel<GP_T, D, GP_NB, false>), dim3(grid), dim3(WGeo::kThreads), 0, stream, a);
       return hipGetLastError();
     }
   }

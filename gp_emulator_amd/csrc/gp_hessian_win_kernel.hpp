@@ -37,6 +37,9 @@
 #ifndef GP_HESS_ABL
 #define GP_HESS_ABL 0
 #endif
+#ifndef GP_HESS_LDS_OUT
+#define GP_HESS_LDS_OUT 1      // 0: the round-2 finish (16-byte stores straight from the accumulators), A/B reference
+#endif
 
 namespace gpk {
 
@@ -85,7 +88,13 @@ template <typename T> __host__ __device__ constexpr int win_row_stride(int D) {
   return (D + 2 + (16 / (int)sizeof(T)) - 1) / (16 / (int)sizeof(T)) * (16 / (int)sizeof(T));
 }
 
-template <typename T, int D, int NB>
+// LDSOUT: the finish assembles the output in LDS and stores whole lines (see the finish); the host picks that
+// instance when the caller's rows are exactly D long (d_actual == D) and 16-byte pieces (win_lds_out), the
+// matrix is 16-byte aligned, and otherwise the instance with the direct stores of round 2.
+template <typename T> __host__ __device__ constexpr bool win_lds_out(int D) {
+  return GP_HESS_LDS_OUT && D % (16 / (int)sizeof(T)) == 0;
+}
+template <typename T, int D, int NB, bool LDSOUT>
 __global__ __launch_bounds__(WGeo::kThreads, (win_wg_per_cu<T>()))
 void hessian_win_kernel(HessMfmaArgs<T> p) {
   typedef Real<T> R;
@@ -104,6 +113,13 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   constexpr int NF = NKS * NBLK;
   constexpr int kChunk = WGeo::kChunk;
   constexpr int NCH = (NF + kChunk - 1) / kChunk;
+  // The finish assembles the wave's output in LDS and writes it as whole lines (below) when the rows of the
+  // matrix are whole 16-byte pieces; the other instances keep the direct stores.
+  constexpr int VW = 16 / (int)sizeof(T);                       // elements per 16 bytes
+  constexpr bool kLdsOut = LDSOUT;
+  static_assert(!LDSOUT || win_lds_out<T>(D), "whole-line stores need matrix rows of whole 16-byte pieces");
+  constexpr int kStageElems = 2 * kChunk * 64 / kWaves;         // a wave's share of the two fragment buffers
+  constexpr int kStagePieces = kChunk * 64 * (int)sizeof(T) / 1024 / (kWaves / 2);   // 1 KiB DMA pieces of chunk 0 in it
 
   __shared__ __attribute__((aligned(16))) T s_xa[NP * DS];
   __shared__ __attribute__((aligned(16))) T s_fr[2][kChunk * 64];
@@ -133,19 +149,38 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   auto load_row = [&](long long grp_) __attribute__((always_inline)) {
     const long long m_ = grp_ * kRowsPerWG + wave * kTile + ml;
     const long long mc_ = m_ < p.M ? m_ : p.M - 1;
+    if constexpr (kLdsOut) {    // d_actual == D: whole rows, 16-byte loads when the rows are aligned
+      const T* row = p.testing + mc_ * D;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int dc = d < p.d_actual ? d : p.d_actual - 1;     // padded dims: sd = centre = 0
-      rraw[d] = p.testing[mc_ * p.d_actual + dc];
+      for (int d = 0; d < D; ++d) rraw[d] = row[d];
+    } else {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int dc = d < p.d_actual ? d : p.d_actual - 1;     // padded dims: sd = centre = 0
+        rraw[d] = p.testing[mc_ * p.d_actual + dc];
+      }
     }
   };
   if ((long long)blockIdx.x < n_groups) load_row(blockIdx.x);
   for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    // chunk 0 goes to buffer 0.  With an even number of chunks per item the previous item's last chunk
-    // sat in buffer 1, and buffer 0's last readers (the chunk before it) passed a barrier since: no
-    // barrier here, the waves of the workgroup may run into the next item a finish apart
-    if constexpr (NCH % 2 == 1) __syncthreads();
-    stage_chunk<T, kWaves, kChunk>(p.pfrags, &s_fr[0][0], wave, lane);
+    // (opaque per item: the pieces' source addresses are then formed with two scalar adds each where they are
+    // used, instead of being hoisted out of the item loop into ~190 scalar registers that live in a vector
+    // register's lanes and come back through v_readlane)
+    const T* pfr = p.pfrags;
+    asm volatile("" : "+s"(pfr));
+    if constexpr (kLdsOut) {
+      // chunk 0 goes to buffer 0, which is also the finish's staging space of waves 0 and 1 (below): each
+      // of the two stages the half of the chunk that lands in its OWN region, as soon as it has left its
+      // own finish -- no barrier here; waves 2 and 3 join at the chunk's barrier
+      if (wave < kWaves / 2)
+        stage_pieces<T, kStagePieces>(pfr, &s_fr[0][0], wave * kStagePieces, lane);
+    } else {
+      // chunk 0 goes to buffer 0.  With an even number of chunks per item the previous item's last chunk
+      // sat in buffer 1, and buffer 0's last readers (the chunk before it) passed a barrier since: no
+      // barrier here, the waves of the workgroup may run into the next item a finish apart
+      if constexpr (NCH % 2 == 1) __syncthreads();
+      stage_chunk<T, kWaves, kChunk>(pfr, &s_fr[0][0], wave, lane);
+    }
 
     T t[D];
     T gm = T(0);
@@ -223,7 +258,9 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       if constexpr (c == 0 && ks % KW == 0 && q > 0) {
         GP_STAMP(2);
         window_weights(std::integral_constant<int, q>{});
-        if constexpr (q == (NKS - 1) / KW) load_row(grp + gridDim.x < n_groups ? grp + gridDim.x : grp);
+        // (kLdsOut: the row is loaded in the finish, once t and G are dead -- carried through the finish it
+        // went to scratch behind a full wait)
+        if constexpr (q == (NKS - 1) / KW && !kLdsOut) load_row(grp + gridDim.x < n_groups ? grp + gridDim.x : grp);
         GP_STAMP(1);
       }
       if constexpr (fl == 0) {
@@ -232,7 +269,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
         if constexpr (!(GP_HESS_ABL & 1)) __syncthreads();  // chunk ch visible; everyone finished reading chunk ch-1
         GP_STAMP(5);
         if constexpr (ch + 1 < NCH && !(GP_HESS_ABL & 8))
-          stage_chunk<T, kWaves, kChunk>(p.pfrags + (ch + 1) * kChunk * 64, &s_fr[(ch + 1) & 1][0], wave, lane);
+          stage_chunk<T, kWaves, kChunk>(pfr + (ch + 1) * kChunk * 64, &s_fr[(ch + 1) & 1][0], wave, lane);
         static_for<kAhead - 1>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           if constexpr (j < kChunk && f + j < NF) afr[j % kAhead] = s_fr[ch & 1][j * 64 + lane];
@@ -287,16 +324,11 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
     // into two dozen registers that the windows would push to scratch
     int da = p.d_actual;
     asm volatile("" : "+s"(da));
-    const long long m = grp * kRowsPerWG + wave * kTile + ml;
-    const bool row_ok = m < p.M;
-    T* out = p.hess + (row_ok ? m : p.M - 1) * (long long)da * da;
-    const bool vec_ok = (da % (16 / (int)sizeof(T)) == 0) && (((unsigned long long)p.hess & 15) == 0);
-    static_for<NBLK>([&](auto cbc) {
+    // block cbv from its accumulator: acc[r] = S2[d][d2] for d = 4 bi + r, d2 = 4 bj + g, test row ml
+    auto block_values = [&](auto cbc, T (&v)[4]) __attribute__((always_inline)) {
       constexpr int cbv = decltype(cbc)::value;
       constexpr int bi = hess_block_bi(cbv), bj = hess_block_bj(cbv);
       const acc_t a = accs[cbv];
-      const int d2 = 4 * bj + g;
-      T v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 4 * bi + r;
@@ -313,6 +345,109 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
           v[r] = x;
         }
       }
+    };
+    if constexpr (kLdsOut) {
+      static_for<NBLK>([&](auto cbc) __attribute__((always_inline)) {      // finish in place
+        T v[4];
+        block_values(cbc, v);
+        accs[decltype(cbc)::value] = acc_t{v[0], v[1], v[2], v[3]};
+      });
+      // every wave has read its last fragment: both fragment buffers are free until chunk 0 of the next
+      // item is staged (by the waves whose staging space it lands in, after their own finish)
+      GP_STAMP(3);
+      __syncthreads();
+      GP_STAMP(6);
+      // Whole-line stores.  Lane (ml, g) holds, over the blocks, complete rows 4 p + g (p = 0 .. NB4 - 1) of
+      // test row ml's matrix: left of the diagonal block as the mirror images of blocks (b, p), b < p, from
+      // it on as the transposed copies of blocks (p, b).  Row block p of all 16 test rows -- 16 runs of
+      // 4 D elements, each contiguous in memory -- is assembled in the wave's share of the fragment
+      // buffers (16-byte pieces, XOR-swizzled by test row so that neither side has bank conflicts), read
+      // back in memory order and stored 16 bytes per lane: every store instruction writes whole 128-byte
+      // lines (1 KiB contiguous per half wave at D = 16) instead of 64 pieces of 64 different lines.
+      typedef T vec_t __attribute__((ext_vector_type(VW)));
+      constexpr int RB16 = D / VW;                     // pieces per matrix row
+      constexpr int PRF = 4 * RB16;                    // pieces per full run
+      constexpr bool kXor = PRF % 8 == 0;
+      constexpr int RS = kXor ? PRF : PRF + 1;         // run stride in pieces (odd when not swizzled)
+      static_assert(kTile * RS * VW <= kStageElems, "a row block of the wave's tile must fit its staging space");
+      vec_t* stg = reinterpret_cast<vec_t*>(&s_fr[0][0] + wave * kStageElems);
+      int lo = lane;                                   // (opaque per item: the piece addresses below are recomputed
+      asm volatile("" : "+v"(lo));                     //  from it with a few integer instructions, not hoisted and spilled)
+      const int mlo = lo & 15, glo = lo >> 4;
+      const long long m0 = grp * kRowsPerWG + wave * kTile;
+      T* out0 = p.hess + m0 * (long long)(D * D);
+      static_for<NB4>([&](auto ppc) __attribute__((always_inline)) {
+        constexpr int pp = decltype(ppc)::value;
+        constexpr int nrows = D - 4 * pp < 4 ? D - 4 * pp : 4;
+        constexpr int PRp = nrows * RB16;              // pieces per run in this row block
+        static_for<NB4>([&](auto bc) __attribute__((always_inline)) {
+          constexpr int b = decltype(bc)::value;
+          T w[4];
+          if constexpr (b < pp) {
+            const acc_t a = accs[hess_block_index(b, pp)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = a[r];
+          } else {
+            const acc_t a = accs[hess_block_index(pp, b)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = a[r];
+            transpose_groups4(w);                      // (cross-lane: executed by every lane)
+            if constexpr (b == pp) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) w[r] = (r <= g) ? a[r] : w[r];
+            }
+          }
+          if (g < nrows) {
+#pragma unroll
+            for (int j = 0; j < 4 / VW; ++j) {
+              if (4 * b + VW * j < D) {
+                const int pi = glo * RB16 + (4 * b) / VW + j;
+                vec_t x;
+#pragma unroll
+                for (int e = 0; e < VW; ++e) x[e] = w[VW * j + e];
+                stg[mlo * RS + (kXor ? (pi ^ (mlo & 7)) : pi)] = x;
+              }
+            }
+          }
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int NCk = kTile * PRp;               // 16-byte pieces of this row block
+        constexpr int NI = (NCk + 63) / 64;
+        vec_t rd[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          const int c = k * 64 + lo;
+          const int row = c / PRp, within = c % PRp;
+          if (NCk % 64 == 0 || c < NCk) rd[k] = stg[row * RS + (kXor ? (within ^ (row & 7)) : within)];
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          const int c = k * 64 + lo;
+          const int row = c / PRp, within = c % PRp;
+#if !(GP_HESS_ABL & 2)
+          if ((NCk % 64 == 0 || c < NCk) && m0 + row < p.M)
+            *reinterpret_cast<vec_t*>(out0 + (long long)row * (D * D) + 4 * pp * D + within * VW) = rd[k];
+#else
+          if (rd[k][0] == T(-12345.678)) out0[0] = rd[k][0];
+#endif
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      load_row(grp + gridDim.x < n_groups ? grp + gridDim.x : grp);     // next item's test row
+    } else {
+    const long long m = grp * kRowsPerWG + wave * kTile + ml;
+    const bool row_ok = m < p.M;
+    T* out = p.hess + (row_ok ? m : p.M - 1) * (long long)da * da;
+    const bool vec_ok = (da % (16 / (int)sizeof(T)) == 0) && (((unsigned long long)p.hess & 15) == 0);
+    static_for<NBLK>([&](auto cbc) {
+      constexpr int cbv = decltype(cbc)::value;
+      constexpr int bi = hess_block_bi(cbv), bj = hess_block_bj(cbv);
+      const int d2 = 4 * bj + g;
+      T v[4];
+      block_values(cbc, v);
 #if GP_HESS_ABL & 2
       if (v[0] + v[1] + v[2] + v[3] == T(-12345.678)) out[0] = v[0];
       if (vec_ok && v[0] == T(-12345.678) && v[1] == T(-1.5))
@@ -344,6 +479,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
         }
       }
     });
+    }
     GP_STAMP(4);
   }
 #if GP_STAMPS

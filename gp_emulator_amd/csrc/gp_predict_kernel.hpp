@@ -376,6 +376,30 @@ __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int 
     }
   }
 }
+// NP consecutive 1 KiB pieces, first_piece .. first_piece + NP - 1 (wave-uniform), by ONE wave: same
+// instruction sequence and contract as stage_chunk.
+template <typename T, int NP>
+__device__ __forceinline__ void stage_pieces(const T* src, T* dst, int first_piece, int lane) {
+  const unsigned voff = (unsigned)lane * 16u;
+  const unsigned lds0 = (unsigned)(uintptr_t)(
+      (__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(dst)));
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pc = first_piece + i;
+    const char* s = reinterpret_cast<const char*>(src) + pc * 1024;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + pc * 1024);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(m0v), "v"(voff), "s"(s)
+        : "memory");
+  }
+}
 // Retire this wave's outstanding LDS-DMA pieces; call right before the barrier that
 // publishes the chunk.
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -30,10 +30,10 @@ ctx.synchronize()
 s = ctx.to_host(d_dbg, (8,), np.uint64).astype(np.float64)
 waves = s[7] / K
 names = ["0 item start: barrier, DMA issue, test row", "1 phase A (all windows)", "2 phase B (matrix instructions, chunk barriers)",
-         "3 s / G from their accumulator slots", "4 finish + stores", "5 chunk boundaries: DMA wait + barrier"]
-tot = s[:6].sum()
+         "3 s / G from their accumulator slots", "4 finish + stores", "5 chunk boundaries: DMA wait + barrier", "6 barrier in front of the whole-line finish"]
+tot = s[:7].sum()
 items_per_wave = (M / (16 * WAVES)) / (waves / WAVES)
 print("N=%d D=%d: waves per launch %.0f, items per wave %.2f" % (N, D, waves, items_per_wave))
-for n, v in zip(names, s[:6]):
+for n, v in zip(names, s[:7]):
     print("%-52s %5.1f %%   %8.0f cycles per item" % (n, 100 * v / tot, v / K / waves / items_per_wave))
 print("total cycles per item (per wave) %.0f" % (tot / K / waves / items_per_wave))
