@@ -305,7 +305,10 @@ def executed_flop_per_point(N, D, kind, minfo, hess_mfma):
             nb4 = (kd + 3) // 4
             if hess_mfma == "win":      # s and G_d ride on the matrix core's spare slots: not in phase A any more
                 phase_a -= 2 * N + 2 * N * D
-            return nb4 * (nb4 + 1) // 2 * 4 * nb * 2048 // 16 + phase_a
+            ksteps = 4 * nb
+            if hess_mfma == "win" and nb in (16, 19) and (N + 3) // 4 == 4 * nb - 1:
+                ksteps -= 1             # the instance that does not issue the all-padding last k-step (N = 300: 75 of 76)
+            return nb4 * (nb4 + 1) // 2 * ksteps * 2048 // 16 + phase_a
         return 2 * 16 * ((N + 15) // 16) * kd * (kd + 1) // 2 + phase_a
     nk = minfo["kernel_nk"]
     issued = sum(1 for J in range(nb) for I in range(J, nb) for s_ in range(4) if 4 * I + s_ < nk)

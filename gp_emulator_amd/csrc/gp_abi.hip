@@ -13,6 +13,7 @@
 #include <cstring>
 #include <exception>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -149,6 +150,8 @@ struct gp_cached_model {
 };
 constexpr int kModelCacheSlots = 4;
 
+static const int kTicketSlots = 256;   // launches that may be in flight at once on a context (the pipeline has 3 slots)
+
 struct gp_ctx {
   int device;
   hipStream_t stream;
@@ -157,6 +160,10 @@ struct gp_ctx {
   void* scratch;
   size_t scratch_bytes;
   void* dbg;   // diagnostic (GP_STAMPS) builds: device buffer for segment cycle sums
+  // item counters of kernels that draw their work items (hessian_win_kernel): a ring of device words, all 0
+  // between launches (the kernel that uses one puts it back to 0), one per launch in flight
+  unsigned* tickets = nullptr;
+  std::atomic<unsigned> ticket_next{0};
   gp_pipe pipe;
   gp_cached_model cache[kModelCacheSlots];
   unsigned long long cache_clock = 0;
@@ -353,6 +360,14 @@ int gp_ctx_create(int device, gp_ctx** out) {
     delete c;
     return fail(GP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
+  e = hipMalloc((void**)&c->tickets, kTicketSlots * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(c->tickets, 0, kTicketSlots * sizeof(unsigned));
+  if (e != hipSuccess) {
+    if (c->tickets) (void)hipFree(c->tickets);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return fail(GP_ERR_HIP, "context item counters: %s", hipGetErrorString(e));
+  }
   *out = c;
   return GP_OK;
 }
@@ -364,6 +379,7 @@ int gp_ctx_destroy(gp_ctx* ctx) {
   for (auto& c : ctx->cache)
     if (c.model) gp_model_destroy(c.model);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->tickets) (void)hipFree(ctx->tickets);
   gp_pipe& pp = ctx->pipe;
   pp.pool.reset();
   for (int k = 0; k < kPipeSlots; ++k) {
@@ -713,6 +729,11 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
     h.use_win = gpk::hess_win<T>(m->kernel_d, m->kernel_nb) && hess_use_win() ? 1 : 0;
     const bool wide = !h.use_win && gpk::hess_wide<T>(m->kernel_d, m->kernel_nb);
     h.dbg = (unsigned long long*)ctx->dbg;
+    h.n_ksteps = (m->n_train + 3) / 4;
+    // items drawn from a counter (see the kernel); GP_HESS_STATIC=1: dealt round-robin as in round 2 (A/B)
+    static const bool static_items = [] { const char* ev = getenv("GP_HESS_STATIC"); return ev && atoi(ev) != 0; }();
+    h.tickets = (h.use_win && !static_items && M < ((int64_t)1 << 36))
+                    ? ctx->tickets + ctx->ticket_next.fetch_add(1) % kTicketSlots : nullptr;
     const int kRowsPerWG = (wide || h.use_win) ? 4 * gpk::kTile : gpk::Geo<T>::kRowsPerWG;   // 4-wave workgroups
     const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG;
     int64_t grid = (int64_t)ctx->compute_units * (h.use_win ? gpk::win_wg_per_cu<T>() : gpk::Geo<T>::kWGPerCU);

@@ -161,6 +161,8 @@ struct HessMfmaArgs {
   int d_actual;
   int use_win;        // hess_wide instances: 1 = hessian_win_kernel (pfrags packed k-step-major), 0 = the wide geometry
   unsigned long long* dbg;   // GP_STAMPS builds only (hessian_win_kernel): [8] segment cycle sums; else unused
+  int n_ksteps;              // ceil(n_train / 4): k-steps that hold training points
+  unsigned* tickets;         // hessian_win_kernel: the launch's item counter (0 on entry and on exit), or null: items dealt round-robin
 };
 
 // Geometry of hessian_mfma_kernel<T, D, NB> (see the header comment).

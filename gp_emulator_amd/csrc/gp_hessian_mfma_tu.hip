@@ -26,6 +26,12 @@ static hipError_t launch_one(const HessMfmaArgs<GP_T>& a, int grid, hipStream_t 
         // whole-line stores through LDS when the caller's rows are exactly D long and the matrix is aligned
         if (a.d_actual == D && (((unsigned long long)a.hess | (unsigned long long)a.testing) & 15) == 0 &&
             !hess_win_direct_stores()) {
+          if constexpr (hess_win_short_last<GP_T>(GP_NB)) {
+            if (a.n_ksteps == 4 * GP_NB - 1) {      // the last k-step holds nothing but padding: not issued
+              hipLaunchKernelGGL((hessian_win_kernel<GP_T, D, GP_NB, true, 3>), dim3(grid), dim3(WGeo::kThreads), 0, stream, a);
+              return hipGetLastError();
+            }
+          }
           hipLaunchKernelGGL((hessian_win_kernel<GP_T, D, GP_NB, true>), dim3(grid), dim3(WGeo::kThreads), 0, stream, a);
           return hipGetLastError();
         }

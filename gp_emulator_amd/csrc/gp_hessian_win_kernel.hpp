@@ -37,6 +37,18 @@
 #ifndef GP_HESS_ABL
 #define GP_HESS_ABL 0
 #endif
+// GP_HESS_PIPE = 1: phase A of window q + 1 is issued UNDER the matrix instructions of window q -- one training
+// point (k-step) of the next window per k-step of the current one, in the same instruction stream: the fp64
+// matrix instructions (ten independent chains, always ready) fill every dependent-issue bubble of the
+// vector chain, so a wave keeps the pipe busy by itself instead of relying on its SIMD partner being in a
+// complementary phase.  Windows are GP_HESS_PIPE_KW k-steps; two window's weights are live (2 x KW registers
+// pairs), one training point in flight.  0: the round-2 order (a window's weights, then its matrix phase).
+#ifndef GP_HESS_PIPE
+#define GP_HESS_PIPE 1
+#endif
+#ifndef GP_HESS_PIPE_KW
+#define GP_HESS_PIPE_KW 10
+#endif
 #ifndef GP_HESS_LDS_OUT
 #define GP_HESS_LDS_OUT 1      // 0: the round-2 finish (16-byte stores straight from the accumulators), A/B reference
 #endif
@@ -94,7 +106,12 @@ template <typename T> __host__ __device__ constexpr int win_row_stride(int D) {
 template <typename T> __host__ __device__ constexpr bool win_lds_out(int D) {
   return GP_HESS_LDS_OUT && D % (16 / (int)sizeof(T)) == 0;
 }
-template <typename T, int D, int NB, bool LDSOUT>
+// KL: live k-steps of the last 16-block (1..4).  The kernel is compiled per block count NB; a training set that
+// leaves the last k-step(s) of its last block empty (N = 300: 75 of 76, N = 250: 63 of 64) runs the instance that
+// issues neither their weights nor their ten matrix instructions (instantiated for the BASELINE shapes only:
+// hess_win_short_last).
+template <typename T> __host__ __device__ constexpr bool hess_win_short_last(int NB) { return NB == 16 || NB == 19; }
+template <typename T, int D, int NB, bool LDSOUT, int KL = 4>
 __global__ __launch_bounds__(WGeo::kThreads, (win_wg_per_cu<T>()))
 void hessian_win_kernel(HessMfmaArgs<T> p) {
   typedef Real<T> R;
@@ -107,8 +124,9 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   constexpr int DSG = row_stride(D);                // packed global image
   constexpr int NB4 = hess_nb4(D);
   constexpr int NBLK = hess_blocks(D);
-  constexpr int NKS = 4 * NB;                                   // k-steps
-  constexpr int NW = GP_HESS_WINDOWS < NKS ? GP_HESS_WINDOWS : NKS;
+  constexpr int NKS = 4 * (NB - 1) + KL;                        // k-steps
+  constexpr bool kPipe = GP_HESS_PIPE != 0;
+  constexpr int NW = kPipe ? (NKS + GP_HESS_PIPE_KW - 1) / GP_HESS_PIPE_KW : (GP_HESS_WINDOWS < NKS ? GP_HESS_WINDOWS : NKS);
   constexpr int KW = (NKS + NW - 1) / NW;                       // k-steps per window (the last may be short)
   constexpr int NF = NKS * NBLK;
   constexpr int kChunk = WGeo::kChunk;
@@ -141,6 +159,8 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long seg_t0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_t0)::"memory");
+  const unsigned long long wave_t0 = seg_t0;
+  const unsigned long long real_t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, one counter for the chip
 #endif
   // the lane's raw test row, loaded one item ahead: at the end of the last window's phase A, when the
   // registers of the training row are free again, so that the HBM latency of these loads is not the
@@ -162,7 +182,31 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
     }
   };
   if ((long long)blockIdx.x < n_groups) load_row(blockIdx.x);
-  for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  // Items (groups of 64 test rows) are DRAWN, not dealt: the two workgroups of a CU do not advance at the same
+  // rate -- the SIMD's arbiter favours the older wave, and with the static round-robin of round 2 the
+  // workgroups dispatched first were through their share at 74 % of the launch while the others carried on
+  // with a SIMD each to themselves (wave lifetimes 4.0 M vs 5.1 M cycles, profiles/r03_hessian_c5.txt).  A
+  // workgroup takes its first item by its index; every further one is gridDim.x + a ticket: one lane draws it
+  // (an atomic add) at the top of the item loop, for the NEXT item; wave 0 hands it to the others through LDS
+  // in front of the item's last chunk barrier -- a store to a wave-uniform address, no control flow inside
+  // the unrolled item -- and every wave reads it in the finish.  Every workgroup draws exactly one ticket
+  // beyond the end, so a launch draws n_groups tickets, and the lane that received the last one puts the
+  // counter back to 0 for the next launch that uses it.  (p.tickets == nullptr: the same flow with the
+  // round-robin numbers.)
+  __shared__ unsigned s_next[1 + kWaves];       // [0] the ticket; [1 + wave] where the other waves' copies go
+  const bool dyn = p.tickets != nullptr;
+  const unsigned last_ticket = (unsigned)(n_groups - 1);
+  unsigned drawn = 0;
+  unsigned pending = ~0u;
+  long long grp = blockIdx.x;
+  while (grp < n_groups) {
+    if (tid == 0) {
+      if (dyn && pending == last_ticket) *(volatile unsigned*)p.tickets = 0u;
+      const unsigned stat = blockIdx.x + drawn * gridDim.x;
+      ++drawn;
+      pending = dyn ? atomicAdd(p.tickets, 1u) : stat;
+    }
+    auto next_grp = [&]() __attribute__((always_inline)) -> long long { return (long long)gridDim.x + s_next[0]; };
     // (opaque per item: the pieces' source addresses are then formed with two scalar adds each where they are
     // used, instead of being hoisted out of the item loop into ~190 scalar registers that live in a vector
     // register's lanes and come back through v_readlane)
@@ -190,7 +234,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       gm = fma(t[d], t[d], gm);
     }
     gm *= T(-0.5);
-    T kvw[KW];                  // the weights of the current window
+    T kvw[kPipe ? 2 : 1][KW];   // the weights of the current window (kPipe: and of the next one)
     acc_t accs[NBLK];
 #pragma unroll
     for (int c = 0; c < NBLK; ++c) accs[c] = acc_t{T(0), T(0), T(0), T(0)};
@@ -240,9 +284,37 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
         for (int u = 0; u < GP; ++u) {
           if constexpr (!R::kExpand) k[u] *= b;
           // (s and G come out of the matrix phase: hess_gslot_*)
-          if (j0 + u < KW && q * KW + j0 + u < NKS) kvw[j0 + u] = k[u] * al[u];
+          if (j0 + u < KW && q * KW + j0 + u < NKS) kvw[kPipe ? q & 1 : 0][j0 + u] = k[u] * al[u];
         }
       });
+    };
+
+    // kPipe: the weight of ONE k-step (the lane's training point of it), into the buffer of its window
+    auto point_weight = [&](auto ksc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      const int i = own_index<T>(ks >> 2, ks & 3, g);
+      const T* row = &s_xa[i * DS];
+      T x[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) x[d] = row[d];
+      const T al = row[D];
+      T k[1];
+      if constexpr (R::kExpand) {
+        k[0] = row[D + 1] + gm;
+#pragma unroll
+        for (int d = 0; d < D; ++d) k[0] = fma(x[d], t[d], k[0]);
+      } else {
+        T r2 = T(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const T dl = x[d] - t[d];
+          r2 = fma(dl, dl, r2);
+        }
+        k[0] = T(-0.5) * r2;
+      }
+      R::template exp_n<1>(k);
+      if constexpr (!R::kExpand) k[0] *= b;
+      kvw[(ks / KW) & 1][ks % KW] = k[0] * al;
     };
 
     constexpr int kAhead = GP_AHEAD;
@@ -255,17 +327,26 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       constexpr int ch = f / kChunk, fl = f % kChunk;
       constexpr int ks = f / NBLK, c = f % NBLK;
       constexpr int q = ks / KW;
-      if constexpr (c == 0 && ks % KW == 0 && q > 0) {
+      if constexpr (kPipe) {
+        // the next window's k-step in the same position, under this k-step's matrix instructions
+        if constexpr (c == 0 && ks + KW < NKS) point_weight(std::integral_constant<int, ks + KW>{});
+      }
+      if constexpr (!kPipe && c == 0 && ks % KW == 0 && q > 0) {
         GP_STAMP(2);
         window_weights(std::integral_constant<int, q>{});
         // (kLdsOut: the row is loaded in the finish, once t and G are dead -- carried through the finish it
         // went to scratch behind a full wait)
-        if constexpr (q == (NKS - 1) / KW && !kLdsOut) load_row(grp + gridDim.x < n_groups ? grp + gridDim.x : grp);
+        if constexpr (q == (NKS - 1) / KW && !kLdsOut) {
+          const long long nx = next_grp();
+          load_row(nx < n_groups ? nx : grp);
+        }
         GP_STAMP(1);
       }
       if constexpr (fl == 0) {
         GP_STAMP(2);
         dma_wait();       // this wave's pieces of chunk ch have landed
+        if constexpr (ch == NCH - 1)      // the next item's ticket (long since returned), published by the barrier below
+          s_next[wave == 0 ? 0 : 1 + wave] = (unsigned)__builtin_amdgcn_readfirstlane((int)pending);
         if constexpr (!(GP_HESS_ABL & 1)) __syncthreads();  // chunk ch visible; everyone finished reading chunk ch-1
         GP_STAMP(5);
         if constexpr (ch + 1 < NCH && !(GP_HESS_ABL & 8))
@@ -277,7 +358,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       }
       if constexpr (fl + kAhead - 1 < kChunk && f + kAhead - 1 < NF)
         afr[(fl + kAhead - 1) % kAhead] = s_fr[ch & 1][(fl + kAhead - 1) * 64 + lane];
-      accs[c] = R::mfma(afr[fl % kAhead], kvw[ks - q * KW], accs[c]);
+      accs[c] = R::mfma(afr[fl % kAhead], kvw[kPipe ? q & 1 : 0][ks - q * KW], accs[c]);
     });
 #if GP_HESS_ABL & 4
     {
@@ -285,6 +366,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
 #pragma unroll
       for (int c = 0; c < NBLK; ++c) sum_ += accs[c][0] + accs[c][1] + accs[c][2] + accs[c][3];
       if (sum_ == T(-12345.678)) p.hess[0] = sum_;
+      grp = next_grp();
       continue;
     }
 #endif
@@ -436,7 +518,10 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
         __builtin_amdgcn_wave_barrier();
       });
       __builtin_amdgcn_sched_barrier(0);
-      load_row(grp + gridDim.x < n_groups ? grp + gridDim.x : grp);     // next item's test row
+      {
+        const long long nx = next_grp();
+        load_row(nx < n_groups ? nx : grp);     // next item's test row
+      }
     } else {
     const long long m = grp * kRowsPerWG + wave * kTile + ml;
     const bool row_ok = m < p.M;
@@ -481,11 +566,32 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
     });
     }
     GP_STAMP(4);
+    grp = next_grp();
   }
+  if (dyn && tid == 0 && pending == last_ticket) *(volatile unsigned*)p.tickets = 0u;
 #if GP_STAMPS
   if (lane == 0 && p.dbg) {
     for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&p.dbg[k_], seg_sum[k_]);
     atomicAdd(&p.dbg[7], 1ull);   // wave count
+#if GP_STAMPS == 2
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_t0)::"memory");
+#endif
+    // [8] shortest, [9] longest, [10] summed wave lifetime; [11] / [12] summed lifetime and count of the waves of the
+    // first gridDim / 2 workgroups (the ones dispatched first: the older wave of each SIMD)
+    atomicMin(&p.dbg[8], seg_t0 - wave_t0);
+    atomicMax(&p.dbg[9], seg_t0 - wave_t0);
+    atomicAdd(&p.dbg[10], seg_t0 - wave_t0);
+    if (blockIdx.x < gridDim.x / 2) {
+      atomicAdd(&p.dbg[11], seg_t0 - wave_t0);
+      atomicAdd(&p.dbg[12], 1ull);
+    }
+    if (tid == 0) atomicAdd(&p.dbg[blockIdx.x < gridDim.x / 2 ? 13 : 14], (unsigned long long)drawn);   // items of the two halves of the grid
+    // [16] earliest / [17] latest wave start, [18] earliest / [19] latest wave end on the chip-wide 100 MHz counter
+    const unsigned long long real_t1 = __builtin_amdgcn_s_memrealtime();
+    atomicMin(&p.dbg[16], real_t0);
+    atomicMax(&p.dbg[17], real_t0);
+    atomicMin(&p.dbg[18], real_t1);
+    atomicMax(&p.dbg[19], real_t1);
   }
 #endif
 }

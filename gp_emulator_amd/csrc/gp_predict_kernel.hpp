@@ -404,7 +404,7 @@ __device__ __forceinline__ void stage_pieces(const T* src, T* dst, int first_pie
 // publishes the chunk.
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-#if GP_STAMPS
+#if GP_STAMPS == 1     // (2: the Hessian kernel's wave lifetimes only -- no stamp inside an item)
 #define GP_STAMP(seg)                                                                    \
   do {                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                   \

@@ -17,17 +17,19 @@ inputs, testing, theta, invQ, invQt = synthetic_inputs(1, N, D, M)
 model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, np.float64)
 d_t = ctx.to_device(testing)
 d_h = ctx.malloc(M * D * D * 8)
-d_dbg = ctx.to_device(np.zeros(8, np.uint64))
+init = np.zeros(24, np.uint64); init[8] = init[16] = init[18] = np.iinfo(np.uint64).max
+d_dbg = ctx.to_device(init)
 _lib.check(ctx.lib.gp_ctx_set_debug_buffer(ctx.h, d_dbg))
 for _ in range(2):
     model.hessian_device(d_t, d_h, M)
 ctx.synchronize()
-ctx.h2d(d_dbg, np.zeros(8, np.uint64))
-K = 5
+ctx.h2d(d_dbg, init)
+K = int(os.environ.get('GP_STAMP_LAUNCHES', '5'))
 for _ in range(K):
     model.hessian_device(d_t, d_h, M)
 ctx.synchronize()
-s = ctx.to_host(d_dbg, (8,), np.uint64).astype(np.float64)
+s = ctx.to_host(d_dbg, (24,), np.uint64).astype(np.float64)
+raw = ctx.to_host(d_dbg, (24,), np.uint64)
 waves = s[7] / K
 names = ["0 item start: barrier, DMA issue, test row", "1 phase A (all windows)", "2 phase B (matrix instructions, chunk barriers)",
          "3 s / G from their accumulator slots", "4 finish + stores", "5 chunk boundaries: DMA wait + barrier", "6 barrier in front of the whole-line finish"]
@@ -37,3 +39,10 @@ print("N=%d D=%d: waves per launch %.0f, items per wave %.2f" % (N, D, waves, it
 for n, v in zip(names, s[:7]):
     print("%-52s %5.1f %%   %8.0f cycles per item" % (n, 100 * v / tot, v / K / waves / items_per_wave))
 print("total cycles per item (per wave) %.0f" % (tot / K / waves / items_per_wave))
+print("wave lifetime per launch (cycles): shortest %.0f  longest %.0f (of the %d launches)  mean %.0f; waves of the first half of the grid: mean %.0f"
+      % (s[8], s[9], K, s[10] / s[7], s[11] / max(s[12], 1)))
+print("items per launch: first half of the grid %.0f, second half %.0f" % (s[13] / K, s[14] / K))
+if K == 1:
+    r0 = int(raw[16])
+    print("one launch, 100 MHz ticks from the earliest wave start: latest start %d, earliest end %d, latest end %d"
+          % (int(raw[17]) - r0, int(raw[18]) - r0, int(raw[19]) - r0))
