@@ -360,8 +360,8 @@ int gp_ctx_create(int device, gp_ctx** out) {
     delete c;
     return fail(GP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
-  e = hipMalloc((void**)&c->tickets, kTicketSlots * sizeof(unsigned));
-  if (e == hipSuccess) e = hipMemset(c->tickets, 0, kTicketSlots * sizeof(unsigned));
+  e = hipMalloc((void**)&c->tickets, 4 * kTicketSlots * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(c->tickets, 0, 4 * kTicketSlots * sizeof(unsigned));
   if (e != hipSuccess) {
     if (c->tickets) (void)hipFree(c->tickets);
     (void)hipStreamDestroy(c->stream);
@@ -732,12 +732,16 @@ static int hessian_device(gp_ctx* ctx, const gp_model* m, const void* d_testing,
     h.n_ksteps = (m->n_train + 3) / 4;
     // items drawn from a counter (see the kernel); GP_HESS_STATIC=1: dealt round-robin as in round 2 (A/B)
     static const bool static_items = [] { const char* ev = getenv("GP_HESS_STATIC"); return ev && atoi(ev) != 0; }();
-    h.tickets = (h.use_win && !static_items && M < ((int64_t)1 << 36))
-                    ? ctx->tickets + ctx->ticket_next.fetch_add(1) % kTicketSlots : nullptr;
+    h.tickets = h.tickets2 = nullptr;
+    if (h.use_win && !static_items && M < ((int64_t)1 << 36)) {      // (two launches per call at most: whole groups, rest)
+      const unsigned slot = ctx->ticket_next.fetch_add(2);
+      h.tickets = ctx->tickets + 4 * (slot % kTicketSlots);            // (4 words per launch: see the kernel)
+      h.tickets2 = ctx->tickets + 4 * ((slot + 1) % kTicketSlots);
+    }
     const int kRowsPerWG = (wide || h.use_win) ? 4 * gpk::kTile : gpk::Geo<T>::kRowsPerWG;   // 4-wave workgroups
     const int64_t groups = (M + kRowsPerWG - 1) / kRowsPerWG;
     int64_t grid = (int64_t)ctx->compute_units * (h.use_win ? gpk::win_wg_per_cu<T>() : gpk::Geo<T>::kWGPerCU);
-    if (grid > groups) grid = groups;
+    if (grid > groups && !h.use_win) grid = groups;      // (the windowed kernel's launcher sizes its own launches)
     hipError_t e = launch_hessm<T>(m->kernel_nb, m->kernel_d, h, (int)grid, stream);
     if (e != hipSuccess) return fail(GP_ERR_HIP, "hessian kernel launch: %s", hipGetErrorString(e));
     return GP_OK;

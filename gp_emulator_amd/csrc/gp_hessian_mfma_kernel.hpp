@@ -162,6 +162,7 @@ struct HessMfmaArgs {
   int use_win;        // hess_wide instances: 1 = hessian_win_kernel (pfrags packed k-step-major), 0 = the wide geometry
   unsigned long long* dbg;   // GP_STAMPS builds only (hessian_win_kernel): [8] segment cycle sums; else unused
   int n_ksteps;              // ceil(n_train / 4): k-steps that hold training points
+  unsigned* tickets2;        // host side only: the counter of the call's second launch (rows beyond the last whole 64-row group)
   unsigned* tickets;         // hessian_win_kernel: the launch's item counter (0 on entry and on exit), or null: items dealt round-robin
 };
 

@@ -49,6 +49,15 @@
 #ifndef GP_HESS_PIPE_KW
 #define GP_HESS_PIPE_KW 10
 #endif
+#ifndef GP_HESS_ROW_EARLY
+#define GP_HESS_ROW_EARLY 0     // 1: next item's row loaded where the last window begins (A/B: 91 registers spilled)
+#endif
+#ifndef GP_HESS_ROW_MID
+#define GP_HESS_ROW_MID 1       // 1: ... in front of row block GP_HESS_ROW_PASS of the finish; 0: behind the finish
+#endif
+#ifndef GP_HESS_ROW_PASS
+#define GP_HESS_ROW_PASS (NB4 > 1 ? NB4 - 2 : 0)     // (one block earlier: 9 registers spilled at D = 16)
+#endif
 #ifndef GP_HESS_LDS_OUT
 #define GP_HESS_LDS_OUT 1      // 0: the round-2 finish (16-byte stores straight from the accumulators), A/B reference
 #endif
@@ -88,7 +97,10 @@ struct WGeo {
   static constexpr int kChunk = 32;
 };
 // workgroups per CU = waves per SIMD (256 registers each; three for fp32 spilled 120 registers)
-template <typename T> __host__ __device__ constexpr int win_wg_per_cu() { return 2; }
+#ifndef GP_HESS_WG_F32
+#define GP_HESS_WG_F32 2
+#endif
+template <typename T> __host__ __device__ constexpr int win_wg_per_cu() { return sizeof(T) == 4 ? GP_HESS_WG_F32 : 2; }
 // Instances that run the windowed kernel: all of them.  It started as the cure for the large fp64
 // instances (hess_wide), but with s and G on the matrix core and the decoupled workgroups it beats the
 // block-major kernel at every compiled shape in both precisions (profiles/r02_hessian_kernels.txt;
@@ -101,8 +113,10 @@ template <typename T> __host__ __device__ constexpr int win_row_stride(int D) {
 }
 
 // LDSOUT: the finish assembles the output in LDS and stores whole lines (see the finish); the host picks that
-// instance when the caller's rows are exactly D long (d_actual == D) and 16-byte pieces (win_lds_out), the
-// matrix is 16-byte aligned, and otherwise the instance with the direct stores of round 2.
+// instance when the caller's rows are exactly D long (d_actual == D) and 16-byte pieces (win_lds_out) and the
+// matrix is 16-byte aligned, and runs it on the whole 64-row groups of the call (M a multiple of 64: no row
+// guards anywhere in it); the rows beyond the last whole group, and every other call, go to the instance with
+// the direct stores of round 2.
 template <typename T> __host__ __device__ constexpr bool win_lds_out(int D) {
   return GP_HESS_LDS_OUT && D % (16 / (int)sizeof(T)) == 0;
 }
@@ -129,6 +143,10 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   constexpr int NW = kPipe ? (NKS + GP_HESS_PIPE_KW - 1) / GP_HESS_PIPE_KW : (GP_HESS_WINDOWS < NKS ? GP_HESS_WINDOWS : NKS);
   constexpr int KW = (NKS + NW - 1) / NW;                       // k-steps per window (the last may be short)
   constexpr int NF = NKS * NBLK;
+  // kPipe, LDSOUT: the k-step at which the next item's test row is loaded: the first of the last window, but behind
+  // the chunk barrier that publishes the next item's number (chunk 1)
+  constexpr int kRowLoadKs0 = (NKS - 1) / KW * KW;
+  constexpr int kRowLoadKs = kRowLoadKs0 * NBLK > 2 * WGeo::kChunk ? kRowLoadKs0 : (NKS - 1);
   constexpr int kChunk = WGeo::kChunk;
   constexpr int NCH = (NF + kChunk - 1) / kChunk;
   // The finish assembles the wave's output in LDS and writes it as whole lines (below) when the rows of the
@@ -169,8 +187,8 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   auto load_row = [&](long long grp_) __attribute__((always_inline)) {
     const long long m_ = grp_ * kRowsPerWG + wave * kTile + ml;
     const long long mc_ = m_ < p.M ? m_ : p.M - 1;
-    if constexpr (kLdsOut) {    // d_actual == D: whole rows, 16-byte loads when the rows are aligned
-      const T* row = p.testing + mc_ * D;
+    if constexpr (kLdsOut) {    // d_actual == D, whole groups: every row exists; 16-byte loads
+      const T* row = p.testing + m_ * D;
 #pragma unroll
       for (int d = 0; d < D; ++d) rraw[d] = row[d];
     } else {
@@ -188,7 +206,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   // with a SIMD each to themselves (wave lifetimes 4.0 M vs 5.1 M cycles, profiles/r03_hessian_c5.txt).  A
   // workgroup takes its first item by its index; every further one is gridDim.x + a ticket: one lane draws it
   // (an atomic add) at the top of the item loop, for the NEXT item; wave 0 hands it to the others through LDS
-  // in front of the item's last chunk barrier -- a store to a wave-uniform address, no control flow inside
+  // in front of the item's second chunk barrier -- a store to a wave-uniform address, no control flow inside
   // the unrolled item -- and every wave reads it in the finish.  Every workgroup draws exactly one ticket
   // beyond the end, so a launch draws n_groups tickets, and the lane that received the last one puts the
   // counter back to 0 for the next launch that uses it.  (p.tickets == nullptr: the same flow with the
@@ -199,7 +217,12 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
   unsigned drawn = 0;
   unsigned pending = ~0u;
   long long grp = blockIdx.x;
+  unsigned items_done = 0;
+#if GP_STAMPS == 2
+  unsigned long long life_ta = 0, life_tb = 0, life_tc = 0;
+#endif
   while (grp < n_groups) {
+    ++items_done;
     if (tid == 0) {
       if (dyn && pending == last_ticket) *(volatile unsigned*)p.tickets = 0u;
       const unsigned stat = blockIdx.x + drawn * gridDim.x;
@@ -330,6 +353,14 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       if constexpr (kPipe) {
         // the next window's k-step in the same position, under this k-step's matrix instructions
         if constexpr (c == 0 && ks + KW < NKS) point_weight(std::integral_constant<int, ks + KW>{});
+        // the next item's test row: loaded where the last window begins -- no weights are formed any more, so
+        // the registers are there, and the window's matrix instructions cover most of the HBM latency
+        if constexpr (GP_HESS_ROW_EARLY && kLdsOut && c == 0 && ks == kRowLoadKs) {
+          __builtin_amdgcn_sched_barrier(0);
+          const long long nx = next_grp();
+          load_row(nx < n_groups ? nx : grp);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if constexpr (!kPipe && c == 0 && ks % KW == 0 && q > 0) {
         GP_STAMP(2);
@@ -345,9 +376,12 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       if constexpr (fl == 0) {
         GP_STAMP(2);
         dma_wait();       // this wave's pieces of chunk ch have landed
-        if constexpr (ch == NCH - 1)      // the next item's ticket (long since returned), published by the barrier below
+        if constexpr (ch == (NCH > 1 ? 1 : 0))   // the next item's ticket (returned by now), published by the barrier below
           s_next[wave == 0 ? 0 : 1 + wave] = (unsigned)__builtin_amdgcn_readfirstlane((int)pending);
         if constexpr (!(GP_HESS_ABL & 1)) __syncthreads();  // chunk ch visible; everyone finished reading chunk ch-1
+#if GP_STAMPS == 2
+        if constexpr (f == 0) life_ta = __builtin_amdgcn_s_memrealtime();
+#endif
         GP_STAMP(5);
         if constexpr (ch + 1 < NCH && !(GP_HESS_ABL & 8))
           stage_chunk<T, kWaves, kChunk>(pfr + (ch + 1) * kChunk * 64, &s_fr[(ch + 1) & 1][0], wave, lane);
@@ -372,6 +406,9 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
 #endif
 
     GP_STAMP(2);
+#if GP_STAMPS == 2
+    life_tb = __builtin_amdgcn_s_memrealtime();
+#endif
     // (everything only the finish needs is formed here, not carried through the windows: the
     // registers are full there, and what does not fit goes to scratch and comes back slowly)
     const T poison = gm - gm;   // NaN for rows holding a NaN or an infinity (exp_ clamps)
@@ -460,6 +497,14 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
       T* out0 = p.hess + m0 * (long long)(D * D);
       static_for<NB4>([&](auto ppc) __attribute__((always_inline)) {
         constexpr int pp = decltype(ppc)::value;
+        if constexpr (GP_HESS_ROW_MID && pp == GP_HESS_ROW_PASS) {
+          // the next item's test row: most accumulators are dead by now, and the remaining row blocks' LDS round
+          // trips and stores cover a part of the HBM latency (loaded earlier it lived in scratch: 91 registers)
+          __builtin_amdgcn_sched_barrier(0);
+          const long long nx = next_grp();
+          load_row(nx < n_groups ? nx : grp);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         constexpr int nrows = D - 4 * pp < 4 ? D - 4 * pp : 4;
         constexpr int PRp = nrows * RB16;              // pieces per run in this row block
         static_for<NB4>([&](auto bc) __attribute__((always_inline)) {
@@ -508,7 +553,7 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
           const int c = k * 64 + lo;
           const int row = c / PRp, within = c % PRp;
 #if !(GP_HESS_ABL & 2)
-          if ((NCk % 64 == 0 || c < NCk) && m0 + row < p.M)
+          if (NCk % 64 == 0 || c < NCk)      // (no row guards: this instance runs whole 64-row groups only)
             *reinterpret_cast<vec_t*>(out0 + (long long)row * (D * D) + 4 * pp * D + within * VW) = rd[k];
 #else
           if (rd[k][0] == T(-12345.678)) out0[0] = rd[k][0];
@@ -517,8 +562,8 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       });
-      __builtin_amdgcn_sched_barrier(0);
-      {
+      if constexpr ((!kPipe || !GP_HESS_ROW_EARLY) && !GP_HESS_ROW_MID) {
+        __builtin_amdgcn_sched_barrier(0);
         const long long nx = next_grp();
         load_row(nx < n_groups ? nx : grp);     // next item's test row
       }
@@ -566,16 +611,31 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
     });
     }
     GP_STAMP(4);
+#if GP_STAMPS == 2
+    life_tc = __builtin_amdgcn_s_memrealtime();
+#endif
     grp = next_grp();
   }
+#if GP_STAMPS == 2
+  if (tid == 0 && p.dbg && items_done > 0 && items_done <= 40) {
+    unsigned long long* rec = p.dbg + 32 + 4 * 512 + 240 * blockIdx.x + 6 * items_done;
+    rec[-4] = life_ta; rec[-3] = life_tb; rec[-2] = life_tc;
+  }
+#endif
   if (dyn && tid == 0 && pending == last_ticket) *(volatile unsigned*)p.tickets = 0u;
 #if GP_STAMPS
+#if GP_STAMPS == 2      // (no atomics here: 2 048 waves adding to the same few words as they leave slow down the workgroups
+                        //  still running by 2-5 x -- an artefact that looked like a property of the launch's end)
+  if (tid == 0 && p.dbg) {
+    p.dbg[32 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    p.dbg[33 + 4 * blockIdx.x] = items_done;
+    p.dbg[34 + 4 * blockIdx.x] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID, bits 3:0
+    p.dbg[35 + 4 * blockIdx.x] = real_t0;
+  }
+#else
   if (lane == 0 && p.dbg) {
     for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&p.dbg[k_], seg_sum[k_]);
     atomicAdd(&p.dbg[7], 1ull);   // wave count
-#if GP_STAMPS == 2
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_t0)::"memory");
-#endif
     // [8] shortest, [9] longest, [10] summed wave lifetime; [11] / [12] summed lifetime and count of the waves of the
     // first gridDim / 2 workgroups (the ones dispatched first: the older wave of each SIMD)
     atomicMin(&p.dbg[8], seg_t0 - wave_t0);
@@ -588,11 +648,18 @@ void hessian_win_kernel(HessMfmaArgs<T> p) {
     if (tid == 0) atomicAdd(&p.dbg[blockIdx.x < gridDim.x / 2 ? 13 : 14], (unsigned long long)drawn);   // items of the two halves of the grid
     // [16] earliest / [17] latest wave start, [18] earliest / [19] latest wave end on the chip-wide 100 MHz counter
     const unsigned long long real_t1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {       // per workgroup: [32 + 4 b] end, items, XCC id, start
+      p.dbg[32 + 4 * blockIdx.x] = real_t1;
+      p.dbg[33 + 4 * blockIdx.x] = items_done;
+      p.dbg[34 + 4 * blockIdx.x] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID, bits 3:0
+      p.dbg[35 + 4 * blockIdx.x] = real_t0;
+    }
     atomicMin(&p.dbg[16], real_t0);
     atomicMax(&p.dbg[17], real_t0);
     atomicMin(&p.dbg[18], real_t1);
     atomicMax(&p.dbg[19], real_t1);
   }
+#endif
 #endif
 }
 

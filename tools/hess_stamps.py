@@ -17,7 +17,7 @@ inputs, testing, theta, invQ, invQt = synthetic_inputs(1, N, D, M)
 model = _lib.Model(ctx, np.exp(theta), inputs, invQt, invQ, np.float64)
 d_t = ctx.to_device(testing)
 d_h = ctx.malloc(M * D * D * 8)
-init = np.zeros(24, np.uint64); init[8] = init[16] = init[18] = np.iinfo(np.uint64).max
+init = np.zeros(32 + 4 * 512 + 240 * 512, np.uint64); init[8] = init[16] = init[18] = np.iinfo(np.uint64).max
 d_dbg = ctx.to_device(init)
 _lib.check(ctx.lib.gp_ctx_set_debug_buffer(ctx.h, d_dbg))
 for _ in range(2):
@@ -28,8 +28,8 @@ K = int(os.environ.get('GP_STAMP_LAUNCHES', '5'))
 for _ in range(K):
     model.hessian_device(d_t, d_h, M)
 ctx.synchronize()
-s = ctx.to_host(d_dbg, (24,), np.uint64).astype(np.float64)
-raw = ctx.to_host(d_dbg, (24,), np.uint64)
+s = ctx.to_host(d_dbg, (32 + 4 * 512 + 240 * 512,), np.uint64).astype(np.float64)
+raw = ctx.to_host(d_dbg, (32 + 4 * 512 + 240 * 512,), np.uint64)
 waves = s[7] / K
 names = ["0 item start: barrier, DMA issue, test row", "1 phase A (all windows)", "2 phase B (matrix instructions, chunk barriers)",
          "3 s / G from their accumulator slots", "4 finish + stores", "5 chunk boundaries: DMA wait + barrier", "6 barrier in front of the whole-line finish"]
@@ -46,3 +46,14 @@ if K == 1:
     r0 = int(raw[16])
     print("one launch, 100 MHz ticks from the earliest wave start: latest start %d, earliest end %d, latest end %d"
           % (int(raw[17]) - r0, int(raw[18]) - r0, int(raw[19]) - r0))
+if K == 1 and raw[33] > 0:
+    wg = raw[32:32 + 4 * 512].reshape(512, 4).astype(np.int64)
+    end = wg[:, 0] - r0
+    print("per workgroup (one launch): end tick percentiles 0/10/50/90/100: %s" % np.percentile(end, [0, 10, 50, 90, 100]).astype(int))
+    for x in sorted(set(wg[:, 2])):
+        sel = wg[:, 2] == x
+        print("  XCC %d: %3d workgroups, items %5d, end ticks min %d median %d max %d; first-half WGs items %d, second-half %d"
+              % (x, sel.sum(), wg[sel, 1].sum(), end[sel].min(), np.median(end[sel]), end[sel].max(),
+                 wg[sel & (np.arange(512) < 256), 1].sum(), wg[sel & (np.arange(512) >= 256), 1].sum()))
+if raw[33] > 0 and os.environ.get("GP_STAMP_DUMP"):
+    np.save(os.environ["GP_STAMP_DUMP"], raw)

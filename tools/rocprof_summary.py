@@ -63,7 +63,7 @@ def main():
     fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
     if fetch or write:
         fk, wk = fetch.get("FETCH_SIZE"), write.get("WRITE_SIZE")
-        tj = {"round": "round 2", "kernel": dom,
+        tj = {"round": os.environ.get("GP_ROUND", "round 3"), "kernel": dom,
               "comment": "HBM bytes per launch, rocprofv3 PMC, one counter per pass, median over the launches after 2 "
                          "warm-ups. FETCH_SIZE is in KiB and on gfx950 reads half the bytes of a coalesced stream "
                          "(MI355X_MICROARCH.md, HBM): x 1024 x 2.  WRITE_SIZE reads exactly: x 1024.",
