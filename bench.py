@@ -88,7 +88,7 @@ def parse():
                     help="timing-only ablation builds (tools/ab_bench.py): do not stop on a parity failure")
     ap.add_argument("--cpu-sample", type=int, default=1000000)
     ap.add_argument("--cpu-procs", type=int, default=0,
-                    help="worker processes of the all-cores CPU leg (0 = the cpu share, at most 16)")
+                    help="worker processes of the all-cores CPU leg (0 = every cpu this process may use)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong (c4 only): fixed --total-rows split over the ranks, host arrays in, "
@@ -98,12 +98,63 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_share():
+def cpu_quota():
+    """cpus this process may really use: the affinity mask, cut down by the cgroup's CFS quota when there is
+    one (cpu.max = "<quota> <period>").  On the 1-GPU MI355X box of this pool: 256 cpus in the mask, a quota of
+    16 -- more worker processes than that only share those 16."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, min(avail, 16))              # the GPU box gives one GPU a 16-cpu share
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return avail, quota
+
+
+def cpu_share():
+    """Worker count of the CPU legs: every cpu this process may use (mask and cgroup quota), at most 256."""
+    avail, quota = cpu_quota()
+    n = avail if quota is None else min(avail, max(1, int(round(quota))))
+    return max(1, min(n, 256))
+
+
+def host_description():
+    """Host facts BASELINE.md section 3 asks for beside a CPU number."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    avail, quota = cpu_quota()
+    out = {"host_cpu_model": model, "host_cpus": int(os.cpu_count() or 0), "cpus_in_affinity_mask": int(avail),
+           "cgroup_cpu_quota": quota, "numpy": np.__version__}
+    try:
+        import scipy
+        out["scipy"] = scipy.__version__
+    except ImportError:
+        pass
+    try:
+        from threadpoolctl import threadpool_info
+        out["blas"] = "; ".join("%s %s (%s threads)" % (i.get("internal_api"), i.get("version"), i.get("num_threads"))
+                                for i in threadpool_info() if i.get("user_api") == "blas")
+    except ImportError:
+        pass
+    return out
 
 
 def cpu_worker(spec):
@@ -149,17 +200,18 @@ def cpu_baseline(sample_rows, procs):
     wall = time.perf_counter() - t0
     if any(w.returncode != 0 for w in ws):
         raise SystemExit("cpu_baseline worker failed")
-    return {"value": sample_rows / dt, "unit": "test-points/s",
+    return dict(host_description(), **{"value": sample_rows / dt, "unit": "test-points/s",
             "cores": int(blas_threads), "kind": "port",
             "sample": "%d rows of the same N=250, D=11 workload in 50k-row blocks, %.1f s; "
-                      "numpy+scipy path (oracle/gp_oracle.py), BLAS threads=%s of %d host "
-                      "cpus, elementwise/cdist/exp single-threaded as in the reference"
+                      "numpy+scipy path (oracle/gp_oracle.py), BLAS threads=%s (every cpu this process may "
+                      "use; the host has %d), elementwise/cdist/exp single-threaded as in the reference"
                       % (sample_rows, dt, blas_threads, os.cpu_count() or 0),
             "all_cores_value": procs * rows_each / max(inner),
             "all_cores_procs": int(procs),
-            "all_cores_sample": "%d single-threaded worker processes x %d rows in 20k-row blocks, slowest "
+            "all_cores_sample": "%d single-threaded worker processes (= every cpu this process may use: affinity "
+                                "mask cut by the cgroup quota) x %d rows in 20k-row blocks, slowest "
                                 "worker %.1f s (%.1f s wall with interpreter start-up)"
-                                % (procs, rows_each, max(inner), wall)}
+                                % (procs, rows_each, max(inner), wall)})
 
 
 WORKLOADS = {
@@ -383,9 +435,7 @@ def bench_strong(a, grp):
     lo, hi = multi_gpu.row_shards(total, world)[rank]
     M = hi - lo
     dtype = np.float64 if a.precision == "f64" else np.float32
-    ndev = _lib.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
+    ndev, n_gpus_used = devices_for(world)
     near = _lib.bind_near_device(grp.local_rank % ndev)      # before the shard's rows are generated
     inputs, _, theta, invQ, invQt = synthetic_inputs(1000, N, D, 1)
     testing = np.empty((M, D))
@@ -420,7 +470,7 @@ def bench_strong(a, grp):
         value = a.steps * total / dt
         outd = {
             "metric": "test-points/sec for predict(mean+var+grad), N_train=300 D=11",
-            "value": value, "unit": "test-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "test-points/s", "n_gpus": n_gpus_used, "ranks": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: N_train=300, D=11, N_test=%d in all, row-sharded over %d "
@@ -486,6 +536,20 @@ def launch_ranks(n_ranks):
     sys.exit(rc)
 
 
+def devices_for(world):
+    """HIP devices visible, and how many of them a ``world``-rank job uses.  A rank needs a device of its own:
+    fewer devices than ranks is an error, unless GP_BENCH_SHARE_GPU=1 (rehearsals of the rank plumbing on a
+    one-GPU box), and then the line reports the devices really used -- ``n_gpus`` never names more GPUs than ran."""
+    from gp_emulator_amd import _lib
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
+    if world > ndev and os.environ.get("GP_BENCH_SHARE_GPU") != "1":
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible (GP_BENCH_SHARE_GPU=1 lets ranks share a "
+                         "device for a rehearsal; the line then reports the devices really used)" % (world, ndev))
+    return ndev, min(world, ndev)
+
+
 def dry_run(a, grp):
     """GP_BENCH_DRY_RUN=1 (tests/test_multi_gpu_cpu.py only): the rank plumbing of a --gpus N run
     without any device work -- rendezvous, barrier, max-reduce, rank 0's line.  The line says so
@@ -529,14 +593,6 @@ def main():
     rank, world = grp.rank, grp.world
     if os.environ.get("GP_BENCH_DRY_RUN") == "1":
         return dry_run(a, grp)
-    ndev = _lib.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
-    share = os.environ.get("GP_BENCH_SHARE_GPU") == "1"      # rehearsals: several ranks on one device, labelled
-    if world > ndev and not share:
-        raise SystemExit("--gpus %d but only %d HIP device(s) visible (GP_BENCH_SHARE_GPU=1 lets ranks share "
-                         "a device for a rehearsal; the line then reports the devices really used)" % (world, ndev))
-    n_gpus_used = min(world, ndev)
     if a.scaling == "strong":
         if a.workload != "c4":
             raise SystemExit("--scaling strong is the c4 workload's mode")
@@ -546,9 +602,7 @@ def main():
     cpu = None
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         cpu = cpu_baseline(a.cpu_sample, a.cpu_procs)
-    ndev = _lib.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs a GPU (no HIP device visible); there is no CPU path")
+    ndev, n_gpus_used = devices_for(world)
     # one process per GPU: run on the cpus next to that GPU (numactl --cpunodebind by hand), so the
     # arrays generated below are first-touched on the socket the device's PCIe root belongs to
     near = _lib.bind_near_device(grp.local_rank % ndev)
@@ -693,7 +747,7 @@ def main():
                          "variance work); hbm_frac = algorithmic bytes against 8 TB/s")}
         out = {
             "metric": metric,
-            "value": value, "unit": "test-points/s", "n_gpus": world, "steps": a.steps,
+            "value": value, "unit": "test-points/s", "n_gpus": n_gpus_used, "ranks": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
@@ -712,11 +766,17 @@ def main():
             roof["e2e_ms_per_call"] = steady * 1e3
             roof["e2e_first_call_ms"] = first * 1e3
             out["end_to_end"] = {"value": rate, "unit": "test-points/s", "ms_per_call": steady * 1e3,
-                                 "first_call_ms": first * 1e3, "rows_per_gpu": M, "n_gpus": world, "threshold": 2e5,
+                                 "first_call_ms": first * 1e3, "rows_per_gpu": M, "n_gpus": n_gpus_used, "threshold": 2e5,
                                  "what": "gp.predict(testing, is_gpu=True) from host numpy arrays to host numpy "
                                          "arrays, median of 10 calls after 3 warm-up calls (PCIe and host copies "
-                                         "included; tests/benchmark.py:41-44); with several ranks all of them "
-                                         "call at once and a call lasts as long as its slowest rank"}
+                                         "included; tests/benchmark.py:41-44); the result arrays are pooled buffers "
+                                         "(_lib.OutputPool: each call's results are dropped before the next call, so "
+                                         "their memory is reused; a caller that KEEPS every result pays ~7 ms of page "
+                                         "faults per 1e6 rows on top, profiles/r02_host_path_experiments.txt); with "
+                                         "several ranks all of them call at once and a call lasts as long as its "
+                                         "slowest rank"}
+            out["warmup_extra"] = ("the 13 host-to-host calls of end_to_end run in front of the --warmup steps (about 45 ms "
+                                   "of device work): the timed region starts at working clocks")
         if cpu is not None:
             out["cpu_baseline"] = cpu
             cpu["gpu_over_cpu"] = value / cpu["value"]          # resident GPU rate / reference-style CPU

@@ -63,6 +63,9 @@ SIGNATURES = {
     "gp_reconstruct_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int]),
     "gp_hessian_host_h64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64]),
     "gp_mv_predict_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    "gp_content_digest": (ctypes.c_uint64, [c_void_p, c_void_p, c_int]),
+    "gp_mv_predict_host_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_int, ctypes.c_uint64]),
     "gp_frag_index": (c_int, [c_int, c_int, c_int, c_int]),
     "gp_likelihood_batch_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -120,6 +123,55 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().gp_last_error_string().decode("utf-8", "replace")
         raise GpuPredictError("%s failed (status %d): %s" % (what or "gp call", rc, msg))
+
+
+GP_STALE = 1     # gp_mv_predict_host_checked: the host data behind a device-resident copy has changed
+
+
+class HostBlocks:
+    """The host arrays a device-resident copy was made from, as the (pointer, length) table the C ABI digests
+    (``gp_content_digest``: a 64-bit digest of every byte, at memory speed, no GPU needed).  ``same_arrays`` is the
+    cheap pre-filter (are these still the very array objects?); ``digest()`` reads the bytes as they are NOW, so an
+    in-place edit of any element shows.  Members that are not C-contiguous arrays (a strided theta column, a
+    list) are digested from a contiguous buffer that ``refresh()`` re-fills from the member: their pointers in the
+    table never change, and a 0.5 MB inverse is never copied unless the caller made it non-contiguous."""
+
+    def __init__(self, arrays):
+        self.arrays = list(arrays)           # the caller's objects themselves
+        self.ids = tuple(id(a) for a in arrays)
+        self._bufs = {}                      # index -> contiguous buffer of a non-contiguous member
+        src = []
+        for i, a in enumerate(self.arrays):
+            if isinstance(a, np.ndarray) and a.flags.c_contiguous:
+                src.append(a)
+            else:
+                self._bufs[i] = np.array(a, order="C", copy=True)
+                src.append(self._bufs[i])
+        self.n = len(src)
+        self.ptrs = (c_void_p * self.n)(*[a.ctypes.data for a in src])
+        self.lens = (c_i64 * self.n)(*[a.nbytes for a in src])
+        self.expected = self.digest()
+
+    def same_arrays(self, arrays):
+        return self.ids == tuple(id(a) for a in arrays)
+
+    def refresh(self):
+        """Before handing ``ptrs`` to a checked call: the non-contiguous members as they are now (a member whose
+        shape has changed no longer fits its buffer: the digest is then made to differ)."""
+        for i, buf in self._bufs.items():
+            a = np.asarray(self.arrays[i])
+            if a.shape == buf.shape and a.dtype == buf.dtype:
+                np.copyto(buf, a)
+            else:
+                buf.view(np.uint8)[...] = 0xA5
+        return self
+
+    def digest(self):
+        self.refresh()
+        return int(load().gp_content_digest(self.ptrs, self.lens, self.n))
+
+    def unchanged(self):
+        return self.digest() == self.expected
 
 
 def device_count():

@@ -39,7 +39,7 @@ def source_digest():
     for d in (CSRC, os.path.join(ROOT, "include")):
         for name in sorted(os.listdir(d)):
             p = os.path.join(d, name)
-            if os.path.isfile(p) and name.endswith((".hip", ".hpp", ".h")):
+            if os.path.isfile(p) and name.endswith((".hip", ".hpp", ".h", ".cpp")):
                 h.update(name.encode())
                 h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
@@ -59,7 +59,7 @@ def _includes(path, seen):
 
 def unit_digest(cmd):
     """Digest of one compile command: its flags plus the source and every header it pulls in."""
-    src = next(a for a in cmd if a.endswith(".hip"))
+    src = next(a for a in cmd if a.endswith((".hip", ".cpp")))
     h = hashlib.sha256(" ".join(cmd).encode())
     for f in sorted(_includes(src, set())):
         h.update(f.encode())
@@ -138,6 +138,9 @@ def _build(force, jobs, verbose, defines, OBJ, LIB, only_units):
                                            "-o", os.path.join(OBJ, "reconstruct.o")])
     tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_train_tu.hip"),
                                            "-o", os.path.join(OBJ, "train.o")])
+    # plain host C++ (no device pass): the content digest with its per-ISA clones
+    tasks.append([HIPCC, "-O3", "-std=c++17", "-fPIC", "-x", "c++", "-c", os.path.join(CSRC, "gp_host_digest.cpp"),
+                  "-o", os.path.join(OBJ, "host_digest.o")])
     abi_obj = os.path.join(OBJ, "gp_abi.o")
     tasks.append([HIPCC] + FLAGS + defines + ["-c", os.path.join(CSRC, "gp_abi.hip"), "-o", abi_obj])
     # biggest kernels first so the pool drains evenly

@@ -1280,9 +1280,42 @@ static int reconstruct_on(gp_ctx* ctx, int dtype, const void* d_basis, const voi
 // the caller's arrays and the device (for these sizes the runtime's own pageable path beats a
 // staged copy: 61 us against 200 us for 2.6 MB of Jacobians).
 constexpr size_t kMvResultMax = (size_t)1 << 30;      // bytes of results per call
+// 64-bit digest of host memory blocks (gp_host_digest.cpp: plain host C++, so that it can be compiled with
+// per-ISA clones): what a device-resident copy of an emulator was made from
+uint64_t gp_host_content_digest(const void* const* blocks, const int64_t* nbytes, int n_blocks);
+// The digest of a list of blocks is defined as that of its two halves (the blocks up to the one that takes the
+// running length past half of the total, and the rest), combined: the halves can then be taken by two threads.
+static inline int digest_split(const int64_t* nbytes, int n_blocks) {
+  int64_t total = 0, run = 0;
+  for (int b = 0; b < n_blocks; ++b) total += nbytes[b];
+  int k = 0;
+  while (k < n_blocks && 2 * run < total) run += nbytes[k++];
+  return k;
+}
+static inline uint64_t digest_combine(uint64_t d0, uint64_t d1) {
+  return (d0 * 0x9E3779B97F4A7C15ull) ^ ((d1 << 31) | (d1 >> 33));
+}
+static uint64_t content_digest(const void* const* blocks, const int64_t* nbytes, int n_blocks, gph::ThreadPool* pool = nullptr) {
+  const int k = digest_split(nbytes, n_blocks);
+  uint64_t d[2];
+  auto half = [&](int t) {
+    d[t] = t == 0 ? gp_host_content_digest(blocks, nbytes, k) : gp_host_content_digest(blocks + k, nbytes + k, n_blocks - k);
+  };
+  if (pool) pool->run(2, half);
+  else { half(0); half(1); }
+  return digest_combine(d[0], d[1]);
+}
+
+struct host_check {      // blocks to digest while the device works, and what the digest must be
+  const void* const* blocks = nullptr;
+  const int64_t* nbytes = nullptr;
+  int n_blocks = 0;
+  uint64_t expected = 0;
+};
+
 template <typename T>
 static int mv_predict_host(gp_ctx* ctx, const gp_model* m, const T* d_basis, const T* y, int64_t M,
-                           int n_bands, T* fwd, T* jac) {
+                           int n_bands, T* fwd, T* jac, const host_check* chk = nullptr) {
   const int D = m->n_inputs, P = m->n_emulators;
   const size_t n_y = (size_t)M * D, n_gp = (size_t)P * M * (2 + D);
   const size_t n_fwd = (size_t)M * n_bands, n_jac = jac ? (size_t)M * D * n_bands : 0;
@@ -1303,6 +1336,16 @@ static int mv_predict_host(gp_ctx* ctx, const gp_model* m, const T* d_basis, con
   const int dtype = sizeof(T) == 8 ? GP_F64 : GP_F32;
   if (!rc) rc = reconstruct_on(ctx, dtype, d_basis, d_mu, d_fwd, M, P, n_bands, st);
   if (!rc && jac) rc = reconstruct_on(ctx, dtype, d_basis, d_der, d_jac, M * D, P, n_bands, st);
+  // While the device works: is the host data the resident copy was made from still what it was?  Between the
+  // launches and the copy back -- a copy into pageable memory does not return before the kernels are through, so
+  // behind it there would be nothing left to hide the digest under -- and with hipStreamQuery first: the runtime
+  // batches what was enqueued above and would otherwise hand it to the device only when somebody waits.
+  bool stale = false;
+  if (!rc && chk && chk->n_blocks > 0) {
+    (void)hipStreamQuery(st);
+    // (two halves, one of them on a helper thread: 45 us alone would outlast the ~35 us the kernels take)
+    stale = content_digest(chk->blocks, chk->nbytes, chk->n_blocks, &host_pool(ctx)) != chk->expected;
+  }
   hipError_t e = hipSuccess;
   const bool one_copy = jac == fwd + n_fwd;             // the caller laid fwd and jac out back to back
   if (!rc) e = hipMemcpyAsync(fwd, d_fwd, (n_fwd + (one_copy ? n_jac : 0)) * sizeof(T), hipMemcpyDeviceToHost, st);
@@ -1312,7 +1355,7 @@ static int mv_predict_host(gp_ctx* ctx, const gp_model* m, const T* d_basis, con
   if (rc) return rc;
   if (e != hipSuccess || es != hipSuccess)
     return fail(GP_ERR_HIP, "mv predict: %s", hipGetErrorString(e != hipSuccess ? e : es));
-  return GP_OK;
+  return stale ? GP_STALE : GP_OK;
 }
 
 extern "C" {
@@ -1530,6 +1573,28 @@ int gp_mv_predict_host(gp_ctx* ctx, const gp_model* model, const void* d_basis, 
   if (model->dtype == GP_F64)
     return guarded([&] { return mv_predict_host<double>(ctx, model, (const double*)d_basis, (const double*)y, n_rows, n_bands, (double*)fwd, (double*)jac); });
   return guarded([&] { return mv_predict_host<float>(ctx, model, (const float*)d_basis, (const float*)y, n_rows, n_bands, (float*)fwd, (float*)jac); });
+}
+
+uint64_t gp_content_digest(const void* const* blocks, const int64_t* nbytes, int n_blocks) {
+  if (!blocks || !nbytes || n_blocks <= 0) return 0;
+  return content_digest(blocks, nbytes, n_blocks);
+}
+
+int gp_mv_predict_host_checked(gp_ctx* ctx, const gp_model* model, const void* d_basis, const void* y,
+                               int64_t n_rows, int n_bands, void* fwd, void* jac,
+                               const void* const* blocks, const int64_t* nbytes, int n_blocks, uint64_t expected) {
+  if (!ctx || !model) return fail(GP_ERR_INVALID, "null context or model");
+  if (n_rows < 0 || n_bands <= 0 || n_blocks < 0) return fail(GP_ERR_INVALID, "bad sizes");
+  if (n_blocks > 0 && (!blocks || !nbytes)) return fail(GP_ERR_INVALID, "null pointer");
+  host_check chk;
+  chk.blocks = blocks; chk.nbytes = nbytes; chk.n_blocks = n_blocks; chk.expected = expected;
+  if (n_rows == 0) return n_blocks > 0 && content_digest(blocks, nbytes, n_blocks) != expected ? GP_STALE : GP_OK;
+  if (!d_basis || !y || !fwd) return fail(GP_ERR_INVALID, "null pointer");
+  if (model->device != ctx->device) return fail(GP_ERR_INVALID, "model lives on device %d, context on %d", model->device, ctx->device);
+  if (!model->d_frags) return fail(GP_ERR_INVALID, "model was created without invQ: no variance operand");
+  if (model->dtype == GP_F64)
+    return guarded([&] { return mv_predict_host<double>(ctx, model, (const double*)d_basis, (const double*)y, n_rows, n_bands, (double*)fwd, (double*)jac, &chk); });
+  return guarded([&] { return mv_predict_host<float>(ctx, model, (const float*)d_basis, (const float*)y, n_rows, n_bands, (float*)fwd, (float*)jac, &chk); });
 }
 
 int gp_likelihood_batch_f64(gp_ctx* ctx, int n_sets, const double* theta, const double* inputs,

@@ -6,8 +6,8 @@
 // large call and kept until gp_ctx_destroy: nothing is spawned per call or per slab.  The
 // calling thread takes part in every job, so a pool of n threads has n - 1 workers.  Tasks
 // of a job are claimed with one atomic add each (dynamic balance: a helper that is
-// descheduled only delays its own task).  Idle workers spin for a few tens of microseconds
-// before they block, because inside a pipelined call the next job arrives that soon.
+// descheduled only delays its own task).  Idle workers spin for about 0.2 ms before they
+// block, because inside a pipelined call, or a loop of small calls, the next job arrives that soon.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -129,7 +129,9 @@ class ThreadPool {
     unsigned long long seen = 0;
     for (;;) {
       // short spin, then block
-      for (int i = 0; i < 4000 && gen_.load(std::memory_order_acquire) == seen; ++i) cpu_relax();
+      // (~0.2 ms: inside a pipelined call the next job arrives within tens of microseconds, and a caller that asks
+      // for one state vector at a time -- whose per-call content check takes one helper -- comes back every ~0.1 ms)
+      for (int i = 0; i < 16000 && gen_.load(std::memory_order_acquire) == seen; ++i) cpu_relax();
       Job* job = nullptr;
       {
         std::unique_lock<std::mutex> lk(mu_);

@@ -50,28 +50,36 @@ def _device_context(device):
         return hit
 
 
-_shard_models = {}      # (device, id(gp), dtype) -> (fingerprint, Model); used under the device's lock
+_shard_models = {}      # (device, id(gp), dtype) -> (weakref to gp, HostBlocks, Model); used under the device's lock
 
 
 def _shard_model(ctx, device, gp, precision):
-    """The emulator packed and uploaded on ``device``, kept between predict_sharded calls (a call per
-    time step of an assimilation re-sends the same emulator).  Re-made when the emulator's arrays
-    are replaced or theta / invQt change; at most eight emulators stay resident per device."""
+    """The emulator packed and uploaded on ``device``, kept between predict_sharded calls (a call per time step
+    of an assimilation re-sends the same emulator).  Keyed by CONTENT: the entry remembers the array objects it
+    was made from and a 64-bit digest of their bytes (``_lib.HostBlocks``; ~10 us for a 250-point emulator) and
+    the digest is re-taken on every call, so replacing theta / inputs / invQt / invQ or editing any of them in
+    place both lead to a re-pack, as in the reference, which uploads the constants on every call
+    (gp_emulator/GaussianProcess.py:289-292).  Entries of emulators that no longer exist are dropped; at most
+    eight emulators stay resident per device."""
+    import weakref
     from . import _lib
+    for k in [k for k, v in list(_shard_models.items()) if k[0] == device and v[0]() is None]:   # dead emulators (ids get reused)
+        _shard_models.pop(k)[2].close()
     key = (device, id(gp), np.dtype(precision).str)
-    fp = (id(gp.inputs), id(gp.invQ), np.asarray(gp.theta).tobytes(), np.asarray(gp.invQt).tobytes())
+    arrays = [gp.theta, gp.inputs, gp.invQt, gp.invQ]
     hit = _shard_models.get(key)
-    if hit is not None and hit[0] == fp:
-        return hit[1]
+    if hit is not None and hit[0]() is gp and hit[1].same_arrays(arrays) and hit[1].unchanged():
+        return hit[2]
     if hit is not None:
-        hit[1].close()
+        hit[2].close()
         del _shard_models[key]
     mine = [k for k in _shard_models if k[0] == device]
     while len(mine) >= 8:
-        _shard_models.pop(mine[0])[1].close()
+        _shard_models.pop(mine[0])[2].close()
         mine.pop(0)
+    blocks = _lib.HostBlocks(arrays)
     model = _lib.Model(ctx, np.exp(gp.theta), gp.inputs, gp.invQt, gp.invQ, precision)
-    _shard_models[key] = (fp, model)
+    _shard_models[key] = (weakref.ref(gp), blocks, model)
     return model
 
 

@@ -144,28 +144,37 @@ class MultivariateEmulator(object):
         return fwd.squeeze()
 
     # ---- the emulator resident on the device ----------------------------------------------------
-    def _fingerprint(self):
-        """What the device-resident copy was made from, cheap enough for the per-call check of a
-        latency path: the identity of every emulator and of its invQ, and the bytes of theta and
-        invQt (any legitimate re-training changes invQt with invQ).  After editing an emulator's
-        arrays IN PLACE call ``release_gpu()``."""
-        return tuple((id(gp), id(gp.invQ), np.asarray(gp.theta).tobytes(), np.asarray(gp.invQt).tobytes())
-                     for gp in self.emulators) + (id(self.basis_functions),)
+    def _host_arrays(self):
+        """Everything the device-resident copy is made from: every emulator's constants and the basis."""
+        out = []
+        for gp in self.emulators:
+            out += [gp.theta, gp.inputs, gp.invQt, gp.invQ]
+        out.append(self.basis_functions)
+        return out
 
     def _gpu_state(self, dt):
+        """The device-resident form of the whole emulator (packed per-PC emulators + basis), rebuilt whenever
+        the host data is no longer what it was made from.  The reference uploads every constant on every call
+        (gpu/predict.cu:11-34), so a caller may replace OR edit in place theta, invQ, invQt, inputs or the basis
+        between two calls and the next call computes with the new values; so it is here: the state remembers the
+        array objects (cheap pre-filter) and a 64-bit digest of all their bytes (``_lib.HostBlocks``), and the
+        digest is re-taken on EVERY call -- inside the library call, while the device works and the calling
+        thread would only wait (``gp_mv_predict_host_checked``), so the latency path pays nothing for it; a
+        mismatch discards that call's results, rebuilds the state and calls again."""
         from . import _lib, perband
         cache = self.__dict__.setdefault("_gpu", {})
         key = (dt.str, _lib.default_device())
-        fp = self._fingerprint()
+        arrays = self._host_arrays()
         st = cache.get(key)
-        if st is not None and st["fp"] == fp:
+        if st is not None and st["blocks"].same_arrays(arrays):
             return st
         if st is not None:
             self._release(st)
             del cache[key]
+        blocks = _lib.HostBlocks(arrays)           # (digest first: what the batch below is packed from)
         batch = perband.make_batch(self.emulators, dt)
         ctx = batch.ctx
-        st = {"fp": fp, "batch": batch, "ctx": ctx,
+        st = {"blocks": blocks, "batch": batch, "ctx": ctx,
               "d_basis": ctx.to_device(np.ascontiguousarray(self.basis_functions, dtype=dt))}
         cache[key] = st
         return st
@@ -210,7 +219,7 @@ class MultivariateEmulator(object):
         from . import _lib
         dt = np.dtype(precision)
         st = self._gpu_state(dt)
-        ctx, batch = st["ctx"], st["batch"]
+        ctx = st["ctx"]
         isz = dt.itemsize
         Yc = np.ascontiguousarray(Y, dtype=dt)
         # one library call per <= 1 GiB of results (rows up, three launches, results down, one
@@ -222,9 +231,21 @@ class MultivariateEmulator(object):
         else:
             fwd = ctx.out_pool.take((M, B), dt)
             jac = ctx.out_pool.take((M, D, B), dt) if do_deriv else None
-        for r0 in range(0, M, step):
+        r0 = 0
+        while r0 < M:
             r1 = min(M, r0 + step)
-            _lib.check(ctx.lib.gp_mv_predict_host(ctx.h, batch.h, st["d_basis"], _lib._ptr(Yc[r0:r1]), r1 - r0, B,
-                                                  _lib._ptr(fwd[r0:r1]), _lib._ptr(jac[r0:r1]) if do_deriv else None),
-                       "gp_mv_predict_host")
+            blocks = st["blocks"].refresh()
+            rc = ctx.lib.gp_mv_predict_host_checked(ctx.h, st["batch"].h, st["d_basis"], _lib._ptr(Yc[r0:r1]), r1 - r0, B,
+                                                    _lib._ptr(fwd[r0:r1]), _lib._ptr(jac[r0:r1]) if do_deriv else None,
+                                                    blocks.ptrs, blocks.lens, blocks.n, blocks.expected)
+            if rc == _lib.GP_STALE:
+                # the host arrays were edited in place since the resident copy was made: rebuild it from what
+                # they hold now and run the same rows again (nothing of the stale call is kept)
+                self._release(st)
+                del self.__dict__["_gpu"][(dt.str, _lib.default_device())]
+                st = self._gpu_state(dt)
+                ctx = st["ctx"]
+                continue
+            _lib.check(rc, "gp_mv_predict_host_checked")
+            r0 = r1
         return (fwd, jac) if do_deriv else fwd

@@ -33,6 +33,8 @@ extern "C" {
 
 typedef enum gp_status {
   GP_OK = 0,
+  GP_STALE = 1,             /* not an error: the host data a device-resident copy was made from has changed
+                               (gp_mv_predict_host_checked); discard the results, rebuild the copy, call again */
   GP_ERR_INVALID = -1,      /* bad argument (null pointer, size <= 0, unsupported shape) */
   GP_ERR_HIP = -2,          /* a HIP runtime call failed (see gp_last_error_string) */
   GP_ERR_NO_DEVICE = -3,    /* no usable GPU */
@@ -222,6 +224,17 @@ int gp_reconstruct_device(gp_ctx* ctx, int dtype, const void* d_basis, const voi
  * of results per call (GP_ERR_UNSUPPORTED beyond: split the rows). */
 int gp_mv_predict_host(gp_ctx* ctx, const gp_model* model, const void* d_basis, const void* y,
                        int64_t n_rows, int n_bands, void* fwd, void* jac);
+
+/* The reference re-uploads every constant on every call (gpu/predict.cu:11-34), so whatever the caller has
+ * done to theta, invQ, invQt or the basis -- in place or not -- is what the call computes with.  A device-resident
+ * copy must not lose that: gp_content_digest is a 64-bit digest of the host memory blocks such a copy was made
+ * from (no GPU needed; every byte counts), and gp_mv_predict_host_checked is gp_mv_predict_host that digests the
+ * same blocks again WHILE THE DEVICE WORKS (the calling thread would only wait) and returns GP_STALE -- with the
+ * results to be discarded and the copy to be rebuilt -- when it is no longer `expected`. */
+uint64_t gp_content_digest(const void* const* blocks, const int64_t* nbytes, int n_blocks);
+int gp_mv_predict_host_checked(gp_ctx* ctx, const gp_model* model, const void* d_basis, const void* y,
+                               int64_t n_rows, int n_bands, void* fwd, void* jac,
+                               const void* const* blocks, const int64_t* nbytes, int n_blocks, uint64_t expected);
 
 /* ---- training objective (next after the predict path: SURVEY.md 8f rank 2) -------------------
  * For each of n_sets hyper-parameter vectors theta [n_sets][n_inputs+2]: what

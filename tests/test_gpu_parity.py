@@ -865,6 +865,87 @@ def test_multivariate_predict_latency_path_and_resident_state(gpu_lib):
     assert np.array_equal(mv.predict(Y[0], do_deriv=False, is_gpu=True), f_new)
 
 
+def test_multivariate_resident_state_follows_in_place_edits(gpu_lib):
+    """The reference uploads every constant on every call (gpu/predict.cu:11-34), so whatever a caller does to
+    an emulator's arrays between two calls -- IN PLACE too -- is what the next call computes with.  The
+    device-resident copy is keyed by content (a digest of all the host arrays, re-taken on every call while
+    the device works): an in-place edit of one element of one invQ, of invQt, of a row of the basis or of theta
+    is followed; an unchanged emulator keeps its resident copy."""
+    from gp_emulator_amd import MultivariateEmulator
+    g = load_golden("prosail_mv")
+    basis = np.array(g["basis_functions"], copy=True)
+    X = g["train_data"].T @ basis
+    mv = MultivariateEmulator(X=X, y=g["y_train"], hyperparams=g["hyperparams"], basis_functions=basis,
+                              n_pcs=int(g["n_pcs"]))
+    y = g["y_train"][3]
+
+    def check(changed):
+        st_before = list(mv._gpu.values())[0] if mv.__dict__.get("_gpu") else None
+        f_cpu, j_cpu = mv.predict(y)
+        f_gpu, j_gpu = mv.predict(y, is_gpu=True)
+        assert np.max(np.abs(f_gpu - f_cpu)) <= 1e-9 * np.max(np.abs(f_cpu))
+        assert np.max(np.abs(j_gpu - j_cpu)) <= 1e-8 * np.max(np.abs(j_cpu))
+        st_after = list(mv._gpu.values())[0]
+        if st_before is not None:
+            assert (st_after is not st_before) == changed
+        return f_gpu
+    f0 = check(False)
+    check(False)                                            # nothing changed: the same resident copy
+    gp2 = mv.emulators[2]
+    gp2.invQ[7, 11] += 1e-3 * np.max(np.abs(gp2.invQ))      # one element of one inverse, in place (only the variance uses it)
+    check(True)
+    gp2.invQt[5] *= 1.5                                     # in place
+    f1 = check(True)
+    assert np.max(np.abs(f1 - f0)) > 1e-9 * np.max(np.abs(f0))
+    mv.basis_functions[1] *= 1.01                           # a row of the basis, in place
+    f2 = check(True)
+    assert np.max(np.abs(f2 - f1)) > 1e-9 * np.max(np.abs(f1))
+    mv.emulators[0].theta[0] += 0.01                        # theta in place (the numpy branch uses the same theta)
+    check(True)
+    check(False)
+    # many rows: same answer as the row-by-row numpy path after all the edits
+    Y = g["y_train"][:5]
+    f_many = mv.predict_many(Y)
+    assert np.max(np.abs(f_many - mv.predict_many(Y, is_gpu=False))) <= 1e-9 * np.max(np.abs(f_many))
+
+
+def test_predict_sharded_follows_in_place_edits(gpu_lib):
+    """predict_sharded keeps the packed emulator on each device between calls, keyed by content: in-place edits
+    of invQ / invQt / theta / inputs and re-assignments are all followed, an unchanged emulator is not re-packed,
+    and a dead emulator's entry never serves another object that happens to get its id."""
+    from gp_emulator_amd import multi_gpu
+    g = synthetic_case("c1_n100_d5")
+    gp = make_gp(dict(g, invQ=g["invQ"].copy(), invQt=g["invQt"].copy(), theta=g["theta"].copy(),
+                      inputs=g["inputs"].copy()))
+    t = g["testing"][:3000]
+
+    def check():
+        ref = gp_oracle.cpu_predict(gp.inputs, gp.theta, gp.invQ, gp.invQt, t)
+        got = multi_gpu.predict_sharded(gp, t, devices=[0, 0])        # two shards on the one device
+        assert max(errs(ref, got)) <= 1e-10
+    check()
+    key = [k for k in multi_gpu._shard_models if k[1] == id(gp)][0]
+    m1 = multi_gpu._shard_models[key][2]
+    check()
+    assert multi_gpu._shard_models[key][2] is m1          # unchanged: reused
+    gp.invQ[3, 17] += 0.5                                 # in place
+    check()
+    assert multi_gpu._shard_models[key][2] is not m1
+    gp.invQt[0] -= 2.0
+    check()
+    gp.theta[1] += 0.2
+    check()
+    gp.inputs[4, 2] += 0.05
+    check()
+    gp.invQ = gp.invQ * 1.0001                            # reassigned
+    check()
+    # a new emulator (possibly at the old one's address) never gets the old one's device copy
+    del gp
+    g2 = synthetic_case("c1_n100_d5")
+    gp = make_gp(dict(g2, theta=g2["theta"] + 0.3))
+    check()
+
+
 def test_multivariate_set_up_on_gpu_and_storage(gpu_lib, tmp_path):
     """All n_pcs inverses in one launch; the emulator then predicts as the host-built one does;
     EmulatorStorage.get_emulator(is_gpu=True) takes the same route."""

@@ -336,3 +336,43 @@ def test_output_pool_reuses_only_unreferenced_buffers():
     assert small.base is None                             # small and oversize requests bypass the pool
     big = pool.take((9 << 20,), np.float64)               # 72 MB > max_item
     assert big.base is None
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py --gpus N without a launcher: it starts its own ranks, and never reports a GPU count it did not run on
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("extra", [[], ["--workload", "c4", "--scaling", "strong"]])
+def test_bench_gpus_2_starts_its_own_ranks(extra):
+    """`python bench.py --gpus 2` with no torch.distributed.run around it: two child ranks rendezvous over gloo,
+    rank 0's line says n_gpus == 2 (GP_BENCH_DRY_RUN=1: rank plumbing only, no device work, labelled so)."""
+    env = dict(os.environ, GP_BENCH_DRY_RUN="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3
+    assert "dry run" in out["data"] and out["value"] == 0.0      # never mistaken for a measurement
+
+
+def test_bench_gpus_mismatch_and_no_gpu_exit_nonzero():
+    """A launcher's WORLD_SIZE that contradicts --gpus is an error, and without a GPU the self-launched job fails as
+    a whole (no line at all) instead of printing a line for fewer GPUs."""
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+    from gp_emulator_amd import _lib
+    try:
+        n = _lib.device_count()
+    except _lib.GpuPredictUnavailable:
+        n = 0
+    if n == 0:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+        assert r.returncode != 0
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -40,3 +40,11 @@ print("predict(y, is_gpu=True)         %8.1f us   max|fwd - numpy| %.1e  max|der
 for m in (1, 16, 1024):
     t, out = timed(lambda: mv.predict_many(Y[:m], do_deriv=True), 50 if m < 1024 else 10)
     print("predict_many(%4d rows, do_deriv) %8.1f us  = %6.1f us per row" % (m, t * 1e6, t * 1e6 / m))
+# the per-call content check (digest of every emulator's constants and the basis, taken while the device works)
+from gp_emulator_amd import _lib  # noqa: E402
+blocks = list(mv._gpu.values())[0]["blocks"]
+t0 = time.perf_counter()
+for _ in range(200):
+    blocks.digest()
+print("digest of the %.1f MB the resident copy was made from, alone on the calling thread: %.1f us"
+      % (sum(blocks.lens) / 1e6, (time.perf_counter() - t0) / 200 * 1e6))
