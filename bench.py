@@ -420,7 +420,26 @@ def e2e_leg(N, D, M, inputs, testing, theta, invQ, invQt, dtype, grp=None):
         ts.append(grp.max(dt) if world > 1 else dt)
         del out
     first, steady = ts[0], float(np.median(ts[3:]))
-    return world * M / steady, steady, first
+    # the same call for a caller that keeps its rows and result arrays page-locked (gp_emulator_amd.pinned_empty):
+    # the library then copies straight between them and the device, no staging, no host copies
+    pinned = None
+    if np.dtype(dtype) == np.float64:
+        import gp_emulator_amd
+        t_pin = gp_emulator_amd.pinned_empty((M, D), dtype)
+        t_pin[...] = testing
+        pout = (gp_emulator_amd.pinned_empty((M,), dtype), gp_emulator_amd.pinned_empty((M,), dtype),
+                gp_emulator_amd.pinned_empty((M, D), dtype))
+        tp = []
+        for k in range(8):
+            if world > 1:
+                grp.barrier()
+            t0 = time.perf_counter()
+            gp.predict(t_pin, is_gpu=True, precision=dtype, out=pout)
+            dt = time.perf_counter() - t0
+            tp.append(grp.max(dt) if world > 1 else dt)
+        pinned = float(np.median(tp[2:]))
+        del t_pin, pout
+    return world * M / steady, steady, first, pinned
 
 
 def bench_strong(a, grp):
@@ -761,7 +780,7 @@ def main():
         }
     if rank == 0:
         if e2e is not None:
-            rate, steady, first = e2e
+            rate, steady, first, pinned_s = e2e
             roof["e2e_points_per_s"] = rate
             roof["e2e_ms_per_call"] = steady * 1e3
             roof["e2e_first_call_ms"] = first * 1e3
@@ -775,7 +794,13 @@ def main():
                                          "faults per 1e6 rows on top, profiles/r02_host_path_experiments.txt); with "
                                          "several ranks all of them call at once and a call lasts as long as its "
                                          "slowest rank"}
-            out["warmup_extra"] = ("the 13 host-to-host calls of end_to_end run in front of the --warmup steps (about 45 ms "
+            if pinned_s:
+                roof["e2e_pinned_points_per_s"] = world * M / pinned_s
+                out["end_to_end"]["pinned_arrays_value"] = world * M / pinned_s
+                out["end_to_end"]["pinned_arrays_ms_per_call"] = pinned_s * 1e3
+                out["end_to_end"]["pinned_arrays_what"] = ("the same call with test rows and out= arrays from "
+                                                           "gp_emulator_amd.pinned_empty: no staging, no host copies")
+            out["warmup_extra"] = ("the 13 + 8 host-to-host calls of end_to_end run in front of the --warmup steps (about 45 ms "
                                    "of device work): the timed region starts at working clocks")
         if cpu is not None:
             out["cpu_baseline"] = cpu

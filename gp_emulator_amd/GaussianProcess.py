@@ -228,7 +228,7 @@ class GaussianProcess:
         assert np.all(ind_end - ind_start <= block_size)
         return ind_start, ind_end
 
-    def gpu_predict(self, testing, precision, threshold):
+    def gpu_predict(self, testing, precision, threshold, out=None):
         """Predict on the GPU in row blocks of at most ``threshold`` rows (reference
         :273-323): constants flattened and cast to ``precision`` once (:289-292), each
         block's rows flattened and cast (:300-311), ``predict_wrap`` called with the twelve
@@ -254,7 +254,9 @@ class GaussianProcess:
             if testing.dtype != np.float64:
                 testing = testing.astype(precision)
             model = self.gpu_model(precision)
-            result, error, deriv = model.predict(testing, max_block_rows=int(threshold))
+            # ``out=(result, error, deriv)``: the caller's own arrays; when they AND ``testing`` are page-locked
+            # (``gp_emulator_amd.pinned_empty``) the library copies straight between them and the device
+            result, error, deriv = model.predict(testing, max_block_rows=int(threshold), out=out)
             if result.dtype != np.float64:   # the reference's outputs are float64 (:318-321)
                 result, error, deriv = (a.astype(np.float64) for a in (result, error, deriv))
             return result, error, deriv
@@ -289,11 +291,12 @@ class GaussianProcess:
             error[block_start:block_end] = error_block
         return result, error, deriv
 
-    def predict(self, testing, do_unc=True, is_gpu=False, precision=np.float64, threshold=2e5):
+    def predict(self, testing, do_unc=True, is_gpu=False, precision=np.float64, threshold=2e5, out=None):
         """Mean, variance and gradient at ``testing`` (n_predict, n_inputs) (reference
-        :327-341).  ``do_unc`` only affects the numpy branch, as in the reference."""
+        :327-341).  ``do_unc`` only affects the numpy branch, as in the reference.  ``out`` (GPU branch only, not in
+        the reference): three arrays to fill instead of pooled ones, e.g. page-locked ones (``pinned_empty``)."""
         if is_gpu == True:  # noqa: E712  (reference spelling, :338)
-            return self.gpu_predict(testing, precision, threshold=threshold)
+            return self.gpu_predict(testing, precision, threshold=threshold, out=out)
         return self.cpu_predict(testing, do_unc)
 
     # ------------------------------------------------------------------ device-resident use

@@ -73,6 +73,8 @@ SIGNATURES = {
                               ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "gp_pack_model_f64": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),
     "gp_pack_model_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 4),
+    "gp_pinned_alloc": (c_int, [c_void_p, c_i64, PP]),
+    "gp_pinned_free": (c_int, [c_void_p, c_void_p]),
     "gp_malloc": (c_int, [c_void_p, c_i64, PP]),
     "gp_free": (c_int, [c_void_p, c_void_p]),
     "gp_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_i64]),
@@ -276,6 +278,23 @@ class Context:
         self.h = h
         self.device = int(device)
         self.out_pool = OutputPool()
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """An uninitialised numpy array in page-locked host memory (``gp_pinned_alloc``; freed with the array).
+        ``Model.predict`` / ``GaussianProcess.predict(is_gpu=True)`` on test rows AND ``out=`` arrays that all live
+        in such memory (model's precision, one emulator, row-major gradient) copies every slab straight between
+        the arrays and the device -- no staging, no host copies, both directions of the link at once."""
+        import weakref
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64))
+        nbytes = max(1, n * dtype.itemsize)
+        ptr = c_void_p()
+        check(self.lib.gp_pinned_alloc(self.h, nbytes, ctypes.byref(ptr)), "gp_pinned_alloc")
+        buf = (ctypes.c_char * nbytes).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=np.uint8, count=n * dtype.itemsize).view(dtype).reshape(shape)
+        lib, h, addr = self.lib, self.h, ptr.value
+        weakref.finalize(buf, lambda: lib.gp_pinned_free(h, c_void_p(addr)))   # when the last view of it is gone
+        return arr
 
     def close(self):
         if getattr(self, "h", None):

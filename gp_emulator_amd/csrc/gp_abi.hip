@@ -129,6 +129,10 @@ struct gp_pipe {
   bool ready = false;
   hipStream_t stream[kPipeSlotsMax] = {};
   hipEvent_t done[kPipeSlotsMax] = {};
+  // one queue per copy direction (see run_slab_pipeline): every slab's rows go up on `up`, every slab's results
+  // come down on `down`, the slot's own stream carries the kernel between two events
+  hipStream_t up = nullptr, down = nullptr;
+  hipEvent_t in_there[kPipeSlotsMax] = {}, computed[kPipeSlotsMax] = {};
   void* stage_in[kPipeSlotsMax] = {};
   void* stage_out[kPipeSlotsMax] = {};
   void* dev[kPipeSlotsMax] = {};
@@ -388,8 +392,12 @@ int gp_ctx_destroy(gp_ctx* ctx) {
     if (pp.stage_out[k]) (void)hipHostFree(pp.stage_out[k]);
     if (pp.dev[k]) (void)hipFree(pp.dev[k]);
     if (pp.done[k]) (void)hipEventDestroy(pp.done[k]);
+    if (pp.in_there[k]) (void)hipEventDestroy(pp.in_there[k]);
+    if (pp.computed[k]) (void)hipEventDestroy(pp.computed[k]);
     if (pp.stream[k]) (void)hipStreamDestroy(pp.stream[k]);
   }
+  if (pp.up) { (void)hipStreamSynchronize(pp.up); (void)hipStreamDestroy(pp.up); }
+  if (pp.down) { (void)hipStreamSynchronize(pp.down); (void)hipStreamDestroy(pp.down); }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return GP_OK;
@@ -870,13 +878,18 @@ static inline void convert_range(TD* dst, const TS* src, size_t lo, size_t hi) {
   else for (size_t i = lo; i < hi; ++i) dst[i] = (TD)src[i];
 }
 
-static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
+// (dev_only_bytes > 0: the slots' device buffers alone -- the pinned-array path stages nothing)
+static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes, size_t dev_only_bytes = 0) {
   gp_pipe& pp = ctx->pipe;
   if (!pp.ready) {
     for (int k = 0; k < kPipeSlots; ++k) {
       if (!pp.stream[k]) HIP_TRY(hipStreamCreateWithFlags(&pp.stream[k], hipStreamNonBlocking));
       if (!pp.done[k]) HIP_TRY(hipEventCreateWithFlags(&pp.done[k], hipEventDisableTiming));
+      if (!pp.in_there[k]) HIP_TRY(hipEventCreateWithFlags(&pp.in_there[k], hipEventDisableTiming));
+      if (!pp.computed[k]) HIP_TRY(hipEventCreateWithFlags(&pp.computed[k], hipEventDisableTiming));
     }
+    if (!pp.up) HIP_TRY(hipStreamCreateWithFlags(&pp.up, hipStreamNonBlocking));
+    if (!pp.down) HIP_TRY(hipStreamCreateWithFlags(&pp.down, hipStreamNonBlocking));
     pp.ready = true;
   }
   // grow-only; a size is recorded only after every slot's buffer exists, so a failed
@@ -893,7 +906,7 @@ static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
     });
     return err;
   };
-  if (pp.stage_in_bytes < in_bytes) {
+  if (dev_only_bytes == 0 && pp.stage_in_bytes < in_bytes) {
     pp.stage_in_bytes = 0;
     for (int k = 0; k < kPipeSlots; ++k) {
       if (pp.stage_in[k]) { void* q = pp.stage_in[k]; pp.stage_in[k] = nullptr; HIP_TRY(hipHostFree(q)); }
@@ -901,7 +914,7 @@ static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
     }
     pp.stage_in_bytes = in_bytes;
   }
-  if (pp.stage_out_bytes < out_bytes) {
+  if (dev_only_bytes == 0 && pp.stage_out_bytes < out_bytes) {
     pp.stage_out_bytes = 0;
     for (int k = 0; k < kPipeSlots; ++k) {
       if (pp.stage_out[k]) { void* q = pp.stage_out[k]; pp.stage_out[k] = nullptr; HIP_TRY(hipHostFree(q)); }
@@ -909,13 +922,14 @@ static int ensure_pipe(gp_ctx* ctx, size_t in_bytes, size_t out_bytes) {
     }
     pp.stage_out_bytes = out_bytes;
   }
-  if (pp.dev_bytes < in_bytes + out_bytes) {
+  const size_t dev_need = dev_only_bytes ? dev_only_bytes : in_bytes + out_bytes;
+  if (pp.dev_bytes < dev_need) {
     pp.dev_bytes = 0;
     for (int k = 0; k < kPipeSlots; ++k) {
       if (pp.dev[k]) { void* q = pp.dev[k]; pp.dev[k] = nullptr; HIP_TRY(hipFree(q)); }
-      HIP_TRY(hipMalloc(&pp.dev[k], in_bytes + out_bytes));
+      HIP_TRY(hipMalloc(&pp.dev[k], dev_need));
     }
-    pp.dev_bytes = in_bytes + out_bytes;
+    pp.dev_bytes = dev_need;
   }
   return GP_OK;
 }
@@ -995,7 +1009,9 @@ static int run_slab_pipeline(gp_ctx* ctx, int64_t M, int64_t slab, size_t in_row
       }
     };
     const int n_tasks = t_in + t_out;
-    if (n_tasks == 1) task(0);
+    static const int skip_host = [] { const char* ev = getenv("GP_HOST_SKIP"); return ev ? atoi(ev) & 8 : 0; }();   // (timing diagnostics only)
+    if (skip_host) {}
+    else if (n_tasks == 1) task(0);
     else host_pool(ctx).run(n_tasks, task);
     auto t2 = now();
     if (has_in) {
@@ -1004,14 +1020,31 @@ static int run_slab_pipeline(gp_ctx* ctx, int64_t M, int64_t slab, size_t in_row
       static const int skip = [] { const char* ev = getenv("GP_HOST_SKIP"); return ev ? atoi(ev) : 0; }();
       T* d_in = (T*)pp.dev[k];
       T* d_out = d_in + in_elems;
+      // The link is full duplex (tools/pcie_duplex.hip: 57 GB/s one way, 2 x 48 GB/s both ways at once) -- but only
+      // for copies that sit in DIFFERENT queues: an upload and a download issued on one stream run one after the
+      // other (26 + 26 GB/s), and with a slab's upload, kernel and download all on its slot's stream the download
+      // of slab s and the upload of slab s + 1 took turns.  So all uploads go on one stream, all downloads on
+      // another, and the slot's stream carries the kernel between two events.
+      static const bool dir_streams = [] { const char* ev = getenv("GP_PIPE_DIRSTREAMS"); return !ev || atoi(ev) != 0; }();
+      hipStream_t s_up = dir_streams ? pp.up : pp.stream[k], s_down = dir_streams ? pp.down : pp.stream[k];
       if (!(skip & 1))
-        e = hipMemcpyAsync(d_in, pp.stage_in[k], sizeof(T) * (size_t)n_in * in_row, hipMemcpyHostToDevice, pp.stream[k]);
+        e = hipMemcpyAsync(d_in, pp.stage_in[k], sizeof(T) * (size_t)n_in * in_row, hipMemcpyHostToDevice, s_up);
       if (e != hipSuccess) break;
+      if (dir_streams) {
+        e = hipEventRecord(pp.in_there[k], s_up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pp.stream[k], pp.in_there[k], 0);
+        if (e != hipSuccess) break;
+      }
       if (!(skip & 2)) rc = launch(d_in, d_out, n_in, pp.stream[k]);
       if (rc) break;
+      if (dir_streams) {
+        e = hipEventRecord(pp.computed[k], pp.stream[k]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_down, pp.computed[k], 0);
+        if (e != hipSuccess) break;
+      }
       if (!(skip & 4))
-        e = hipMemcpyAsync(pp.stage_out[k], d_out, sizeof(T) * (size_t)n_in * out_row, hipMemcpyDeviceToHost, pp.stream[k]);
-      if (e == hipSuccess) e = hipEventRecord(pp.done[k], pp.stream[k]);
+        e = hipMemcpyAsync(pp.stage_out[k], d_out, sizeof(T) * (size_t)n_in * out_row, hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipEventRecord(pp.done[k], s_down);
     }
     if (trace) {
       auto t3 = now();
@@ -1022,12 +1055,86 @@ static int run_slab_pipeline(gp_ctx* ctx, int64_t M, int64_t slab, size_t in_row
   }
   // leave every stream idle whatever happened (the buffers are reused by the next call)
   for (int k = 0; k < kPipeSlots; ++k) (void)hipStreamSynchronize(pp.stream[k]);
+  (void)hipStreamSynchronize(pp.up);
+  (void)hipStreamSynchronize(pp.down);
   if (trace)
     fprintf(stderr, "[gp host pipeline] rows=%lld slab=%lld slabs=%lld threads=%d: total %.3f ms = event waits %.3f + host copies %.3f + enqueue %.3f\n",
             (long long)M, (long long)slab, (long long)ns, host_threads(),
             std::chrono::duration<double>(now() - t_begin).count() * 1e3, t_wait * 1e3, t_copy * 1e3, t_enq * 1e3);
   if (rc) return rc;
   if (e != hipSuccess) return fail(GP_ERR_HIP, "host pipeline: %s", hipGetErrorString(e));
+  return GP_OK;
+}
+
+// Is [p, p + bytes) page-locked host memory the device can copy to / from directly (gp_pinned_alloc,
+// hipHostMalloc, hipHostRegister)?  Pageable memory makes hipPointerGetAttributes fail: not an error here.
+static bool is_pinned_host(const void* p, size_t bytes) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (a.type != hipMemoryTypeHost) return false;
+  hipPointerAttribute_t b;      // (the last byte too: a registered range may end inside the array)
+  if (hipPointerGetAttributes(&b, (const char*)p + (bytes ? bytes - 1 : 0)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return b.type == hipMemoryTypeHost;
+}
+
+// The host-pointer path for a caller whose rows AND result arrays are page-locked (gp_pinned_alloc): no staging
+// and no host copies at all -- every slab's rows go from the caller's array to the device and its results straight
+// into the caller's arrays (row-major gradient, one emulator), uploads and downloads on their own streams so that
+// the two directions of the link run at once.  What the slab pipeline spends on 384 MB of host copies per 1e6 rows
+// (the main thread's critical path, tools/r03_host_matrix.sh) is gone, and with it the host-DRAM traffic that
+// limits several GPUs streaming at once.
+template <typename T>
+static int predict_host_pinned(gp_ctx* ctx, const gp_model* m, const T* testing, T* result, T* error, T* deriv,
+                               int64_t M, int64_t max_rows) {
+  const int D = m->n_inputs;
+  // Slabs of four rounds of the persistent grid (131 072 rows in fp64) behind a short run-up of one and two rounds
+  // (so that the first results are on their way down after ~0.1 ms).  A slab costs one upload and three downloads
+  // (mean, variance, gradient: three arrays of the caller's); between two copies on one stream the copy engine
+  // idles ~10 us, and copies of less than a few MB do not reach the link's rate anyway (tools/pcie_duplex.hip:
+  // 1 MB pieces 33 GB/s per direction, 6 MB pieces 45).  Measured: slabs doubling up to eight rounds 2.83 ms per
+  // 1e6 rows (while the slabs grow, a slab's results are down before the next, twice as long, upload and kernel
+  // are through), the two small downloads on a second download stream 3.30 ms (it contends with the first).
+  // max_rows bounds the slabs.
+  constexpr int64_t kRowsPerWG = gpk::Geo<T>::kRowsPerWG;
+  const int64_t round = (int64_t)ctx->compute_units * gpk::Geo<T>::kWGPerCU * kRowsPerWG;
+  int64_t cap = 4 * round;
+  if (max_rows > 0 && cap > max_rows) cap = max_rows < kRowsPerWG ? kRowsPerWG : max_rows / kRowsPerWG * kRowsPerWG;
+  const size_t in_elems = (size_t)cap * D, out_elems = (size_t)cap * (2 + D);
+  int rc = ensure_pipe(ctx, 0, 0, (in_elems + out_elems) * sizeof(T));
+  if (rc) return rc;
+  gp_pipe& pp = ctx->pipe;
+  hipError_t e = hipSuccess;
+  int64_t s0 = 0, cur = round < cap ? round : cap;
+  for (int64_t s = 0; s0 < M && e == hipSuccess && rc == GP_OK; ++s) {
+    const int k = (int)(s % kPipeSlots);
+    const int64_t n = s0 + cur <= M ? cur : M - s0;
+    if (s >= kPipeSlots) e = hipEventSynchronize(pp.done[k]);       // the slot's device buffers are free again
+    if (e != hipSuccess) break;
+    T* d_in = (T*)pp.dev[k];
+    T* d_mu = d_in + in_elems;
+    T* d_var = d_mu + n;
+    T* d_der = d_var + n;
+    e = hipMemcpyAsync(d_in, testing + (size_t)s0 * D, sizeof(T) * (size_t)n * D, hipMemcpyHostToDevice, pp.up);
+    if (e == hipSuccess) e = hipEventRecord(pp.in_there[k], pp.up);
+    if (e == hipSuccess) e = hipStreamWaitEvent(pp.stream[k], pp.in_there[k], 0);
+    if (e != hipSuccess) break;
+    rc = predict_device<T>(ctx, m, d_in, d_mu, d_var, d_der, n, GP_DERIV_ROWMAJOR, pp.stream[k]);
+    if (rc) break;
+    e = hipEventRecord(pp.computed[k], pp.stream[k]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(pp.down, pp.computed[k], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(deriv + (size_t)s0 * D, d_der, sizeof(T) * (size_t)n * D, hipMemcpyDeviceToHost, pp.down);
+    if (e == hipSuccess) e = hipMemcpyAsync(result + s0, d_mu, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, pp.down);
+    if (e == hipSuccess) e = hipMemcpyAsync(error + s0, d_var, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, pp.down);
+    if (e == hipSuccess) e = hipEventRecord(pp.done[k], pp.down);
+    s0 += n;
+    if (2 * cur <= cap) cur *= 2;
+  }
+  for (int k = 0; k < kPipeSlots; ++k) (void)hipStreamSynchronize(pp.stream[k]);
+  (void)hipStreamSynchronize(pp.up);
+  (void)hipStreamSynchronize(pp.down);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(GP_ERR_HIP, "host pipeline (pinned arrays): %s", hipGetErrorString(e));
   return GP_OK;
 }
 
@@ -1071,6 +1178,13 @@ static int predict_host(gp_ctx* ctx, const gp_model* m, const TH* testing, TH* r
     if (e != hipSuccess || es != hipSuccess)
       return fail(GP_ERR_HIP, "predict (direct copies): %s", hipGetErrorString(e != hipSuccess ? e : es));
     return GP_OK;
+  }
+  if constexpr (sizeof(T) == sizeof(TH)) {
+    static const bool no_pinned = [] { const char* ev = getenv("GP_NO_PINNED_PATH"); return ev && atoi(ev) != 0; }();
+    if (!no_pinned && E == 1 && layout == GP_DERIV_ROWMAJOR &&
+        is_pinned_host(testing, (size_t)M * D * sizeof(T)) && is_pinned_host(result, (size_t)M * sizeof(T)) &&
+        is_pinned_host(error, (size_t)M * sizeof(T)) && is_pinned_host(deriv, (size_t)M * D * sizeof(T)))
+      return predict_host_pinned<T>(ctx, m, (const T*)testing, (T*)result, (T*)error, (T*)deriv, M, max_rows);
   }
   const int64_t slab = slab_rows<T>(ctx, m, M, (int64_t)out_row, max_rows);
   // float64 rows for a float32 model: centre and scale in double, round once (the kernel then
@@ -1640,6 +1754,30 @@ int gp_likelihood_batch_f64(gp_ctx* ctx, int n_sets, const double* theta, const 
   return GP_OK;
 }
 
+int gp_pinned_alloc(gp_ctx* ctx, int64_t bytes, void** ptr) {
+  if (!ctx || !ptr) return fail(GP_ERR_INVALID, "null pointer");
+  if (bytes <= 0) return fail(GP_ERR_INVALID, "bytes must be positive");
+  HIP_TRY(hipSetDevice(ctx->device));
+  // by a helper thread: they run on the cpus next to the device, so the pages are first touched on its NUMA node
+  hipError_t err = hipSuccess;
+  const int dev = ctx->device;
+  void* q = nullptr;
+  host_pool(ctx).run_on_worker([&] {
+    err = hipSetDevice(dev);
+    if (err == hipSuccess) err = hipHostMalloc(&q, (size_t)bytes, hipHostMallocDefault);
+    if (err == hipSuccess) std::memset(q, 0, (size_t)bytes);
+  });
+  if (err != hipSuccess) return fail(GP_ERR_HIP, "gp_pinned_alloc(%lld bytes): %s", (long long)bytes, hipGetErrorString(err));
+  *ptr = q;
+  return GP_OK;
+}
+int gp_pinned_free(gp_ctx* ctx, void* ptr) {
+  if (!ctx) return fail(GP_ERR_INVALID, "null context");
+  if (!ptr) return GP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipHostFree(ptr));
+  return GP_OK;
+}
 int gp_malloc(gp_ctx* ctx, int64_t bytes, void** dptr) {
   if (!ctx || !dptr) return fail(GP_ERR_INVALID, "null pointer");
   if (bytes <= 0) return fail(GP_ERR_INVALID, "bytes must be positive");

@@ -265,6 +265,15 @@ int gp_pack_model_f32(const float* expX, const float* inputs, const float* invQt
                       const float* invQ, int n_train, int n_inputs, int theta_size,
                       float* xa, float* frags, float* sd, float* b);
 
+/* Page-locked host memory for callers that keep their test rows and result arrays in it: gp_predict_host (one
+ * emulator, row-major gradient, arrays of the model's precision) recognises such arrays (gp_pinned_alloc,
+ * hipHostMalloc or hipHostRegister -- by hipPointerGetAttributes) and copies every slab straight between them and the
+ * device: no staging, no host copies, uploads and downloads on their own streams so that both directions of the
+ * link run at once.  (The reference copies out of and into the caller's pageable numpy arrays with blocking
+ * cudaMemcpy, gpu/predict.cu:11-34, 73, 117, 150.)  Allocated on the NUMA node the context's device hangs off. */
+int gp_pinned_alloc(gp_ctx* ctx, int64_t bytes, void** ptr);
+int gp_pinned_free(gp_ctx* ctx, void* ptr);
+
 /* ---- device memory and timing plumbing (so the Python host needs no GPU framework) --- */
 int gp_malloc(gp_ctx* ctx, int64_t bytes, void** dptr);
 int gp_free(gp_ctx* ctx, void* dptr);

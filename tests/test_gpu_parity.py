@@ -909,6 +909,41 @@ def test_multivariate_resident_state_follows_in_place_edits(gpu_lib):
     assert np.max(np.abs(f_many - mv.predict_many(Y, is_gpu=False))) <= 1e-9 * np.max(np.abs(f_many))
 
 
+@pytest.mark.parametrize("prec", [np.float64, np.float32])
+def test_pinned_arrays_skip_the_staging_and_give_the_same_bits(gpu_lib, prec):
+    """Test rows and result arrays in page-locked memory (pinned_empty) go straight to and from the device
+    (gp_predict_host recognises them): same bits as the staged path on pageable arrays, ragged last slab, guard
+    elements untouched, and a mix of pinned and pageable arrays quietly takes the staged path."""
+    import gp_emulator_amd
+    g = synthetic_case("c2_n250_d11")
+    gp = make_gp(g)
+    M, D = 70001, g["inputs"].shape[1]                       # > the small-call limit, not a multiple of anything
+    rs = np.random.RandomState(4)
+    rows = rs.random_sample((M, D)).astype(prec)
+    ref = gp.gpu_model(prec).predict(rows)                    # pageable in, pooled out: the staged pipeline
+    t_pin = gp_emulator_amd.pinned_empty((M + 2, D), prec)
+    t_pin[1:-1] = rows
+    mu = gp_emulator_amd.pinned_empty((M + 2,), prec)
+    var = gp_emulator_amd.pinned_empty((M + 2,), prec)
+    der = gp_emulator_amd.pinned_empty((M + 2, D), prec)
+    for a in (mu, var, der):
+        a[...] = -7.0
+    out = gp.gpu_model(prec).predict(t_pin[1:-1], out=(mu[1:-1], var[1:-1], der[1:-1]))
+    for r, o in zip(ref, out):
+        assert np.array_equal(r, o)
+    assert mu[0] == mu[-1] == var[0] == var[-1] == -7.0 and np.all(der[0] == -7.0) and np.all(der[-1] == -7.0)
+    # GaussianProcess.predict(out=...) -- float64 arrays only go straight through when the model is float64
+    if prec == np.float64:
+        got = gp.predict(t_pin[1:-1], is_gpu=True, out=(mu[1:-1], var[1:-1], der[1:-1]))
+        assert got[0].base is not None and np.array_equal(got[0], ref[0])
+        oracle = gp_oracle.cpu_predict(g["inputs"], g["theta"], g["invQ"], g["invQt"], rows[:2000].astype(np.float64))
+        assert max(errs(oracle, [a[:2000] for a in got])) <= 1e-10
+    # mixed: pageable results with pinned rows -> the staged path, same bits
+    out2 = gp.gpu_model(prec).predict(t_pin[1:-1])
+    for r, o in zip(ref, out2):
+        assert np.array_equal(r, o)
+
+
 def test_predict_sharded_follows_in_place_edits(gpu_lib):
     """predict_sharded keeps the packed emulator on each device between calls, keyed by content: in-place edits
     of invQ / invQt / theta / inputs and re-assignments are all followed, an unchanged emulator is not re-packed,
