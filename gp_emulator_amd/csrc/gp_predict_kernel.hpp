@@ -59,6 +59,9 @@ namespace gpk {
 // (second accumulator) on top of 4: 1.442 -- not kept.  fp32: no difference.
 #define GP_AHEAD 4
 #endif
+#ifndef GP_MU_DOUBLE
+#define GP_MU_DOUBLE 1    // 0: the mean's sum in the compute type (A/B: fp32 accuracy on ill-conditioned emulators, speed)
+#endif
 #ifndef GP_ESTRIN
 #define GP_ESTRIN 0     // 1: Estrin form of the exp polynomial (A/B: slower, more registers)
 #endif
@@ -352,6 +355,9 @@ __device__ __forceinline__ void stage_chunk(const T* src, T* dst, int wave, int 
   constexpr int kBytes = kChunk * 64 * (int)sizeof(T);
   constexpr int kPieces = kBytes / 1024;          // 1 KiB per wave-instruction
   static_assert(kPieces * 1024 == kBytes, "chunk must be whole 1 KiB pieces");
+  // (round 3, tried: waves 0..3 -- one per SIMD -- issuing all the pieces, the others running the same
+  // instructions with EXEC = 0, so that a wave's SIMD partner keeps the matrix pipe busy while it issues:
+  // 1.456 vs 1.435 ms on config 2, fp64 -- the four issuing waves then run behind at every chunk barrier)
   // wave-uniform SGPR source base, 32-bit per-lane VGPR offset (saddr form); piece pc goes
   // to wave (pc mod kWaves)
   const unsigned voff = (unsigned)lane * 16u;
@@ -553,7 +559,15 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 
     GP_STAMP(1);   // test rows loaded and scaled
     T kv[NK];
+    // the mean's sum runs in double in BOTH precisions: on an ill-conditioned emulator (sum |k a| / |mean| ~ 1e5 on
+    // PROSAIL) float32 accumulation of the float32 products is what the float32 kernel loses first (mean error
+    // 9.7e-4 -> 4.7e-4 of max|mean| with the sum alone in double; what is left is k_i itself, computed in float32);
+    // two fp64-rate instructions per training point
+#if GP_MU_DOUBLE
+    double mu = 0.0;
+#else
     T mu = T(0);
+#endif
     T ga[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) ga[d] = T(0);
@@ -620,7 +634,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
 #pragma unroll
       for (int u = 0; u < GU; ++u) {
         const T w = k[u] * al[u];
-        mu += w;
+        mu += (decltype(mu))w;
 #if GP_ABLATE == 2
         ga[u % D] += w;
 #else
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
     });
     GP_STAMP(2);   // phase A proper
     // (batches of 6: a whole-array batch raises the live-register peak enough to spill)
-    mu = xor_reduce_groups(mu) + poison;
+    const T mu_t = (T)xor_reduce_groups(mu) + poison;
     static_for<(D + 5) / 6>([&](auto bc) {
       constexpr int d0 = decltype(bc)::value * 6;
       constexpr int nb_ = (D - d0 < 6) ? (D - d0) : 6;
@@ -643,11 +657,11 @@ __global__ __launch_bounds__(Geo<T>::kThreads, Geo<T>::kWavesPerSimd) void predi
       for (int d = 0; d < D; ++d) sdv[d] = s_sd[d];
 #pragma unroll
       for (int d = 0; d < D; ++d)
-        ga[d] = sdv[d] * (R::kExpand ? fma(-t[d], mu, ga[d]) : ga[d]);
+        ga[d] = sdv[d] * (R::kExpand ? fma(-t[d], mu_t, ga[d]) : ga[d]);
     }
 
     if (m < p.M) {
-      if (g == 0) o_mu[m] = mu;
+      if (g == 0) o_mu[m] = mu_t;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if ((d & 3) == g && d < p.d_actual) {
