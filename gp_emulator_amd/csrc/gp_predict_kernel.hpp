@@ -86,8 +86,11 @@ constexpr int kTile = 16;            // test rows per wave tile (MFMA N dimensio
 template <typename T> struct Geo {
   static constexpr int kWaves = sizeof(T) == 8 ? GP_WAVES : GP_WAVES_F32;  // per workgroup
   static constexpr int kThreads = kWaves * 64;
-  static constexpr int kWavesPerSimd = kWaves >= 8 ? kWaves / 4 : 2;  // launch bound
-  static constexpr int kWGPerCU = kWaves >= 8 ? 1 : 8 / kWaves;
+#ifndef GP_WG_PER_CU_SMALL
+#define GP_WG_PER_CU_SMALL 0    // > 0: workgroups per CU when a workgroup is four waves (one per SIMD), else 8 / waves
+#endif
+  static constexpr int kWGPerCU = kWaves >= 8 ? 1 : (GP_WG_PER_CU_SMALL > 0 ? GP_WG_PER_CU_SMALL : 8 / kWaves);
+  static constexpr int kWavesPerSimd = kWaves >= 8 ? kWaves / 4 : kWGPerCU * kWaves / 4;  // launch bound
   static constexpr int kRowsPerWG = kWaves * kTile;
   // A-operand fragments per LDS chunk (double-buffered: 2 x kChunk x 64 reals of LDS)
   static constexpr int kChunk = sizeof(T) == 8 ? GP_CHUNK : GP_CHUNK_F32;

@@ -337,3 +337,49 @@ def test_host_training_objective_numpy_branch():
     assert np.max(np.abs(gp.partial_devs(theta))) < 1e-3
     mu, var, der = gp.predict(g["smooth_inputs"][:5])
     assert np.max(np.abs(mu - g["smooth_targets"][:5])) < 0.1
+
+
+def test_content_digest_sees_every_byte_and_host_blocks_follow_edits():
+    """gp_content_digest (no GPU): the digest the device-resident copies are keyed by.  Any single-byte change in
+    any block changes it, block boundaries and lengths count, unaligned and odd-length blocks work; HostBlocks
+    re-reads strided members and lists on every digest."""
+    import ctypes
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+
+    def digest(arrs):
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        lens = (ctypes.c_int64 * len(arrs))(*[a.nbytes for a in arrs])
+        return int(lib.gp_content_digest(ptrs, lens, len(arrs)))
+    blocks = [rs.random_sample(n) for n in (1, 7, 31, 32, 33, 250 * 250, 13)] + [rs.bytes(37), rs.bytes(8)]
+    blocks = [np.frombuffer(b, np.uint8).copy() if isinstance(b, bytes) else b for b in blocks]
+    d0 = digest(blocks)
+    assert d0 == digest([b.copy() for b in blocks]) and d0 != 0
+    for bi, b in enumerate(blocks):                      # one byte of every block, first / middle / last
+        raw = b.view(np.uint8)
+        for pos in {0, raw.size // 2, raw.size - 1}:
+            raw[pos] ^= 1
+            assert digest(blocks) != d0, (bi, pos)
+            raw[pos] ^= 1
+    assert digest(blocks) == d0
+    assert digest(blocks[::-1]) != d0                    # order counts
+    assert digest(blocks[:-1] + [blocks[-1][:4], blocks[-1][4:]]) != d0      # so do the block boundaries
+    odd = np.frombuffer(rs.bytes(8 * 40 + 3), np.uint8)[3:]                    # an unaligned block
+    assert digest([odd]) == digest([odd.copy()])
+    # HostBlocks: contiguous arrays by pointer, a strided column and a list through re-filled buffers
+    H = rs.random_sample((12, 13))
+    a, lst = rs.random_sample((50, 50)), [1.0, 2.0, 3.0]
+    hb = _lib.HostBlocks([a, H[:, 3], lst])
+    assert hb.unchanged() and hb.same_arrays([a, H[:, 3], lst]) is False      # (a fresh slice is a new object)
+    col = H[:, 3]
+    hb = _lib.HostBlocks([a, col, lst])
+    assert hb.same_arrays([a, col, lst]) and hb.unchanged()
+    a[17, 4] += 1e-12
+    assert not hb.unchanged()
+    a[17, 4] -= 1e-12
+    H[5, 3] *= 2.0
+    assert not hb.unchanged()
+    H[5, 3] /= 2.0
+    assert hb.unchanged()
+    lst[2] = 4.0
+    assert not hb.unchanged()

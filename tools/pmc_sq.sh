@@ -26,7 +26,7 @@ for f in glob.glob(out + '/p*/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         dur[r['Kernel_Name']].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
 # dominant kernel = largest total duration
-k = max(dur, key=lambda n: sum(dur[n]))
+k = max((n for n in dur if 'gpk::' in n), key=lambda n: sum(dur[n]))
 print('kernel', k[:110])
 print('launches', len(dur[k]), 'mean ms under the counters %.4f' % (sum(dur[k]) / len(dur[k])))
 for c, v in sorted(acc[k].items()):

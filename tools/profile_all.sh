@@ -5,7 +5,7 @@
 # the host-path timings, the strong-scaling rehearsal and the reference benchmark flow.
 # Everything lands under gpurun_out/<tag>_final/; copy what is to be judged into profiles/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/${TAG}_final
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -16,6 +16,7 @@ python3 bench.py --workload c3 --steps 5 --warmup 2 > $OUT/c3_f64_bench.json
 python3 bench.py --workload c4 --steps 10 --warmup 3 > $OUT/c4_f64_bench.json
 python3 bench.py --workload c5 --steps 20 --warmup 5 > $OUT/c5_f64_bench.json
 python3 bench.py --workload c5 --precision f32 --steps 20 --warmup 5 > $OUT/c5_f32_bench.json
+GP_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/c2_f64_2ranks_one_gpu.json
 python3 bench.py --workload mv --steps 5 --warmup 2 > $OUT/mv_f64_bench.json
 python3 bench.py --workload train --steps 10 --warmup 3 > $OUT/train_f64_bench.json
 python3 bench.py --workload train --emulators 1 --steps 30 --warmup 5 > $OUT/train1_f64_bench.json
@@ -38,7 +39,8 @@ python3 tools/host_path_timing.py --c4 > $OUT/host_path_timing.txt 2>&1
 echo "== strong scaling rehearsal (ranks share the one GPU of this box)" >&2
 python3 bench.py --workload c4 --scaling strong --total-rows 10000000 --steps 3 --warmup 1 > $OUT/strong_1rank_1e7.json
 for n in 2 4; do
-  python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --workload c4 --scaling strong --total-rows 10000000 --steps 3 --warmup 1 > $OUT/strong_${n}ranks_1e7.json 2>> $OUT/strong.err
+  # (bench.py starts its own ranks; GP_BENCH_SHARE_GPU=1: the ranks share this box's one GPU -- the line then says n_gpus 1, ranks n)
+  GP_BENCH_SHARE_GPU=1 python3 bench.py --gpus $n --workload c4 --scaling strong --total-rows 10000000 --steps 3 --warmup 1 > $OUT/strong_${n}ranks_1e7.json 2>> $OUT/strong.err
 done
 python3 bench.py --workload c4 --scaling strong --total-rows 100000000 --steps 2 --warmup 1 > $OUT/strong_1rank_1e8.json
 echo "== reference benchmark flow" >&2
