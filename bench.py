@@ -499,13 +499,14 @@ def bench_strong(a, grp):
                        "parallelism": "row-sharded x%d, host gather, no collective" % world,
                        "device": info["name"], "host_threads_per_rank": ctx.host_threads(),
                        "cpus_bound_near_gpu": len(near)},
-            "roofline": {"bound": "hbm", "achieved": value * 192 / 1e9, "peak": PEAK_HBM_GBPS * world, "unit": "GB/s",
-                         "frac": value * 192 / 1e9 / (PEAK_HBM_GBPS * world), "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": value * 192 / 1e9, "peak": PEAK_HBM_GBPS * n_gpus_used, "unit": "GB/s",
+                         "frac": value * 192 / 1e9 / (PEAK_HBM_GBPS * n_gpus_used), "traffic": None,
                          "kernel": "predict_kernel<%s,11,75> behind the host slab pipeline" % ("double" if a.precision == "f64" else "float"),
-                         "pcie_gbps_per_gpu": value * 192 / 1e9 / world,
-                         "note": "host-to-host: bound by PCIe (192 B per point over a link that moved 55-62 GB/s "
-                                 "for both directions together on the 1-GPU box, profiles/r02_host_path_experiments.txt) "
-                                 "and by host DRAM when several GPUs stream at once, not by HBM or the fp64 pipe"},
+                         "pcie_gbps_per_gpu": value * 192 / 1e9 / n_gpus_used,
+                         "note": "host-to-host: bound by PCIe (192 B per point over a full-duplex link: 57 GB/s one way, "
+                                 "2 x 48 GB/s both ways at once, profiles/r03_pcie_duplex.txt; the staged pipeline reaches "
+                                 "~65 GB/s for both directions together) and by host DRAM when several GPUs stream at once, "
+                                 "not by HBM or the fp64 pipe"},
             "parity": {"worst_over_ranks": worst, "tol": tol, "checked_rows_per_rank": 1024},
         }
         print(json.dumps(outd), flush=True)

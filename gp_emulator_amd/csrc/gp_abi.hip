@@ -1025,19 +1025,21 @@ static int run_slab_pipeline(gp_ctx* ctx, int64_t M, int64_t slab, size_t in_row
       // other (26 + 26 GB/s), and with a slab's upload, kernel and download all on its slot's stream the download
       // of slab s and the upload of slab s + 1 took turns.  So all uploads go on one stream, all downloads on
       // another, and the slot's stream carries the kernel between two events.
-      static const bool dir_streams = [] { const char* ev = getenv("GP_PIPE_DIRSTREAMS"); return !ev || atoi(ev) != 0; }();
-      hipStream_t s_up = dir_streams ? pp.up : pp.stream[k], s_down = dir_streams ? pp.down : pp.stream[k];
+      // (GP_PIPE_DIRSTREAMS: bit 0 = uploads on their own stream, bit 1 = downloads on their own stream; default 3)
+      static const int dir_streams = [] { const char* ev = getenv("GP_PIPE_DIRSTREAMS"); return ev ? atoi(ev) : 3; }();
+      const bool own_up = dir_streams & 1, own_down = dir_streams & 2;
+      hipStream_t s_up = own_up ? pp.up : pp.stream[k], s_down = own_down ? pp.down : pp.stream[k];
       if (!(skip & 1))
         e = hipMemcpyAsync(d_in, pp.stage_in[k], sizeof(T) * (size_t)n_in * in_row, hipMemcpyHostToDevice, s_up);
       if (e != hipSuccess) break;
-      if (dir_streams) {
+      if (own_up) {
         e = hipEventRecord(pp.in_there[k], s_up);
         if (e == hipSuccess) e = hipStreamWaitEvent(pp.stream[k], pp.in_there[k], 0);
         if (e != hipSuccess) break;
       }
       if (!(skip & 2)) rc = launch(d_in, d_out, n_in, pp.stream[k]);
       if (rc) break;
-      if (dir_streams) {
+      if (own_down) {
         e = hipEventRecord(pp.computed[k], pp.stream[k]);
         if (e == hipSuccess) e = hipStreamWaitEvent(s_down, pp.computed[k], 0);
         if (e != hipSuccess) break;

@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256, 2) void probe(double* out, unsigned long long*
         for (int k = 0; k < 4; ++k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(xf) : "v"((float)a));
       }
       x = xf;
+    } else if constexpr (MODE == 8) {     // 10 mfma on ONE accumulator (a dependent chain, as predict_kernel's phase B)
+#pragma unroll
+      for (int i = 0; i < 10; ++i) MFMA(acc[0]);
+    } else if constexpr (MODE == 9) {     // 10 mfma alternating between TWO accumulators
+#pragma unroll
+      for (int i = 0; i < 10; ++i) MFMA(acc[i & 1]);
     } else if constexpr (MODE == 7) {     // 40 dependent v_fma_f32 alone
       float xf = (float)x;
 #pragma unroll
@@ -100,6 +106,8 @@ int main() {
     if (run<5>("interleaved: (2 mfma, 8 chain steps) x 5", w, d_out, d_cyc)) return 1;
     if (run<6>("interleaved: (1 mfma, 4 dependent v_fma_f32) x 10", w, d_out, d_cyc)) return 1;
     if (run<7>("40-step dependent v_fma_f32 chain", w, d_out, d_cyc)) return 1;
+    if (run<8>("10 mfma_f64 on ONE accumulator (dependent chain)", w, d_out, d_cyc)) return 1;
+    if (run<9>("10 mfma_f64 alternating between two accumulators", w, d_out, d_cyc)) return 1;
   }
   return 0;
 }

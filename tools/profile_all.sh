@@ -35,7 +35,7 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 bench.py --workload train --steps 12 --warmup 4 > /dev/null 2>> $OUT/rocprof.log
 cp $(ls $OUT/trace_train/*/*kernel_stats.csv | head -1) $OUT/train_f64_kernel_stats.csv; rm -rf $OUT/trace_train
 echo "== host path" >&2
-python3 tools/host_path_timing.py --c4 > $OUT/host_path_timing.txt 2>&1
+python3 tools/host_path_timing.py --c4 --bind > $OUT/host_path_timing.txt 2>&1
 echo "== strong scaling rehearsal (ranks share the one GPU of this box)" >&2
 python3 bench.py --workload c4 --scaling strong --total-rows 10000000 --steps 3 --warmup 1 > $OUT/strong_1rank_1e7.json
 for n in 2 4; do
