@@ -20,8 +20,9 @@
 //     v_mfma_f64_16x16x4_f64:  tile += C^T W,  C[k][i] = -s_i p_k w^(k)_i,  W[k][j] = w^(k)_j,
 //     both operands read from the LDS panels (all 38 reads of a wave first, then its 34 matrix
 //     instructions back to back, no branch between the tiles); finally the finished pivot rows /
-//     columns (a third panel, s_F) replace the corresponding registers.  Two barriers per pass:
-//     the next pass stages its pivot rows into s_R, which the update phase never reads;
+//     columns (a third panel, s_F) replace the corresponding registers and, in the same sweep over
+//     the tiles, the NEXT pass's pivot rows are staged (round 3: one test per tile instead of four).
+//     Two barriers per pass: the staging writes s_R, which the update phase never reads;
 //   * Q itself is built straight into the tiles; invQt = invQ t is summed from the finished tiles in
 //     registers (row sums inside the owning wave, column sums through a per-wave LDS strip, added in
 //     wave order); the lower triangle of the inverse is written to global memory once (the mirror
@@ -30,6 +31,10 @@
 //
 // Work per theta: 32 passes x 17 tiles x 2 matrix instructions per wave; the per-pass panel steps
 // are latency-bound and run on one wave / 256 threads while the others wait at the barrier.
+// Running the steps of pass p + 1 beside the matrix instructions of pass p ("look-ahead") was built twice in
+// round 3 and measured slower both times (profiles/r03_train_kernel.txt): an fp64 matrix instruction holds a
+// SIMD's pipe for 64 cycles and no vector instruction runs beside it, so the steps' dependent chain, sharing its
+// SIMD with a wave that issues matrix instructions back to back, advances one instruction per 64 cycles.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gp_predict_kernel.hpp"
@@ -65,6 +70,22 @@ constexpr int tmB = 8;             // pivots per pass (== tkB)
   } while (0)
 #else
 #define TM_STAMP(seg) do { } while (0)
+#endif
+// GP_TRAIN_STAMPS=2: the anatomy of a pass instead -- 1 rows -> LDS (nothing with GP_TRAIN_MERGED_SWEEP), 2 the barrier
+// in front of the steps, 3 steps + barrier, 4 operand reads of the update, 5 its matrix instructions, 6 pivot rows /
+// columns replaced (+ the next pass's rows -> LDS), 7 everything behind the passes; wave GP_TRAIN_STAMP_WAVE of workgroup 0.
+#ifndef GP_TRAIN_STAMP_WAVE
+#define GP_TRAIN_STAMP_WAVE 0
+#endif
+#if GP_TRAIN_STAMPS == 2
+#define TM_FINE(seg) TM_STAMP(seg)
+#define TM_COARSE(seg) do { } while (0)
+#else
+#define TM_FINE(seg) do { } while (0)
+#define TM_COARSE(seg) TM_STAMP(seg)
+#endif
+#ifndef GP_TRAIN_MERGED_SWEEP
+#define GP_TRAIN_MERGED_SWEEP 1  // a pass's finished rows / columns and the next pass's staging in ONE sweep over the tiles
 #endif
 
 template <int DM>
@@ -114,7 +135,9 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
   double tl[tmTiles][4];
   static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;
-    const int R = tile_R(t), C = tile_C(t);
+    int wv = w;
+    asm volatile("" : "+s"(wv));           // (a tile's coordinates are read for that tile: shared between the tiles of a
+    const int R = t <= wv ? wv : tmNB - 1 - wv, C = t <= wv ? t : t - wv - 1;   // block row they stay live, 16 DM registers)
     const int j = 16 * C + ml;
     double xj[DM];
     static_for<DM>([&](auto dc) __attribute__((always_inline)) {
@@ -133,6 +156,9 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
       const double q = b * exp(-0.5 * r2) + (i == j ? noise : 0.0);
       tl[t][r] = (i < N && j < N) ? q : (i == j ? 1.0 : 0.0);
     });
+    // the tile is FINISHED here, before the next one's coordinates are read: left to the scheduler, every tile's LDS
+    // reads go first and their results are spilled until the arithmetic gets to them
+    asm volatile("" : "+v"(tl[t][0]), "+v"(tl[t][1]), "+v"(tl[t][2]), "+v"(tl[t][3]));
   });
 
   // ---- in-place Gauss-Jordan inversion, 8 pivots per pass --------------------------------------
@@ -140,48 +166,84 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
   // compile-time constant: the registers that hold pivot rows (2 h and 2 h + 1 of a tile) must be
   // named statically or the tiles would be addressed, i.e. live in scratch memory.
   TM_STAMP(0);
+  // Which of this wave's tiles a pass touches specially (all wave-uniform):
+  //   tiles [tlo, thi] lie in the pivots' block row (this wave owns it, else the range is empty);
+  //   tiles t1 / t2 are the ones BELOW the pivot block in its block column (rows w / 15 - w);
+  //   the diagonal tile of the pivot block is thi;
+  // and the same as bit masks over the tile index: one scalar bit test per tile and question.
+  struct PassGeo { int Ib, tlo, t1; unsigned rowmask, belowmask, colmask; };
+  auto geo_of = [&](const int k0, const int wv) __attribute__((always_inline)) {
+    PassGeo q;
+    q.Ib = k0 >> 4;                   // block row of the pivots
+    const int own = (q.Ib == wv) ? 0 : (q.Ib == tmNB - 1 - wv) ? 1 : -1;
+    q.tlo = own == 0 ? 0 : own == 1 ? wv + 1 : 1;
+    const int thi = own == 0 ? wv : own == 1 ? tmNB : 0;
+    q.t1 = q.Ib < wv ? q.Ib : -1;
+    const int t2 = q.Ib < tmNB - 1 - wv ? wv + 1 + q.Ib : -1;
+    q.rowmask = own < 0 ? 0u : ((2u << thi) - 1u) & ~((1u << q.tlo) - 1u);
+    q.belowmask = (q.t1 >= 0 ? 1u << q.t1 : 0u) | (t2 >= 0 ? 1u << t2 : 0u);
+    q.colmask = q.belowmask | (own < 0 ? 0u : 1u << thi);     // + the diagonal tile
+    return q;
+  };
+  const int lrow = g * tmLd + ml;              // this lane's offset inside a panel row pair
+  // (1) a tile's share of the 8 pivot rows -> s_R.  Columns up to the pivot block come from the tiles of block
+  // row Ib (registers 2 h and 2 h + 1 hold rows 8 h + g and 8 h + 4 + g); columns right of it from
+  // the pivot COLUMNS of the tiles below, A[k][j] = A[j][k] while neither is eliminated.
+  auto stage_tile = [&](auto tc, auto hc, const PassGeo& q, const int wv) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int h = decltype(hc)::value;
+    if (q.rowmask & (1u << t)) {
+      const int C = t - q.tlo;
+      s_R[lrow + 16 * C] = tl[t][2 * h];
+      s_R[lrow + 4 * tmLd + 16 * C] = tl[t][2 * h + 1];
+    }
+    if (q.belowmask & (1u << t)) {
+      const int R = t == q.t1 ? wv : tmNB - 1 - wv;
+      if ((ml >> 3) == h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_R[(ml & 7) * tmLd + 16 * R + g + 4 * r] = tl[t][r];
+      }
+    }
+  };
+  // (5) a tile's finished pivot rows and columns (from s_F) into its registers
+  auto replace_tile = [&](auto tc, auto hc, const PassGeo& q, const int wv, const int k0) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int h = decltype(hc)::value;
+    const int R = t <= wv ? wv : tmNB - 1 - wv, C = t <= wv ? t : t - wv - 1;
+    if (q.rowmask & (1u << t)) {                // pivot rows of this tile
+      tl[t][2 * h] = s_F[lrow + 16 * C];
+      tl[t][2 * h + 1] = s_F[lrow + 4 * tmLd + 16 * C];
+    }
+    if (q.colmask & (1u << t)) {                // pivot columns: the signed transpose of the rows
+      if ((ml >> 3) == h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int il = g + 4 * r, i = 16 * R + il;
+          const bool pivot_row = (R == q.Ib) && ((il >> 3) == h);
+          if (!pivot_row) {
+            const double rv = s_F[(ml & 7) * tmLd + i];
+            tl[t][r] = (i < k0) ? rv : -rv;
+          }
+        }
+      }
+    }
+  };
   auto pass = [&](const int k0, auto hc) __attribute__((always_inline)) {
     constexpr int h = decltype(hc)::value;
-    const int Ib = k0 >> 4;           // block row of the pivots
-    // Which of this wave's tiles a pass touches specially (all wave-uniform):
-    //   tiles [tlo, thi] lie in the pivots' block row (this wave owns it, else the range is empty);
-    //   tiles t1 / t2 are the ones BELOW the pivot block in its block column (rows w / 15 - w);
-    //   the diagonal tile of the pivot block is thi.
+    typedef std::integral_constant<int, 1 - h> HN;
     // wv is made opaque once per pass: everything derived from it (tile coordinates, LDS
     // addresses) is then recomputed per pass with a few scalar instructions instead of being
     // hoisted out of the pass loop into ~100 registers, which would push tiles into scratch.
     int wv = w;
     asm volatile("" : "+s"(wv));
-    const int own = (Ib == wv) ? 0 : (Ib == tmNB - 1 - wv) ? 1 : -1;
-    const int tlo = own == 0 ? 0 : own == 1 ? wv + 1 : 1;
-    const int thi = own == 0 ? wv : own == 1 ? tmNB : 0;
-    const int t1 = Ib < wv ? Ib : -1;
-    const int t2 = Ib < tmNB - 1 - wv ? wv + 1 + Ib : -1;
-    // the same as bit masks over the tile index: one scalar bit test per tile and question
-    const unsigned rowmask = own < 0 ? 0u : ((2u << thi) - 1u) & ~((1u << tlo) - 1u);
-    const unsigned belowmask = (t1 >= 0 ? 1u << t1 : 0u) | (t2 >= 0 ? 1u << t2 : 0u);
-    const unsigned colmask = belowmask | (own < 0 ? 0u : 1u << thi);     // + the diagonal tile
-    const int lrow = g * tmLd + ml;              // this lane's offset inside a panel row pair
-    // (1) the 8 pivot rows -> s_R.  Columns up to the pivot block come from the tiles of block row
-    // Ib (registers 2 h and 2 h + 1 hold rows 8 h + g and 8 h + 4 + g); columns right of it from
-    // the pivot COLUMNS of the tiles below, A[k][j] = A[j][k] while neither is eliminated.
-    static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value;
-      if (rowmask & (1u << t)) {
-        const int C = t - tlo;
-        s_R[lrow + 16 * C] = tl[t][2 * h];
-        s_R[lrow + 4 * tmLd + 16 * C] = tl[t][2 * h + 1];
-      }
-      if (belowmask & (1u << t)) {
-        const int R = t == t1 ? wv : tmNB - 1 - wv;
-        if ((ml >> 3) == h) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s_R[(ml & 7) * tmLd + 16 * R + g + 4 * r] = tl[t][r];
-        }
-      }
-    });
+    const PassGeo q = geo_of(k0, wv);
+#if !GP_TRAIN_MERGED_SWEEP
+    static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) { stage_tile(tc, hc, q, wv); });
+#endif
+    TM_FINE(1);
     __syncthreads();
-    TM_STAMP(1);
+    TM_COARSE(1);
+    TM_FINE(2);
     // (2) + (3) the 8 scalar steps on the panel, one thread per column (waves 0..3).  Every wave
     // also carries the 8 x 8 pivot block, column c in lane c, and takes each step's pivot row out
     // of it with v_readlane (scalar registers): no LDS round trip and no barrier between the steps
@@ -238,8 +300,16 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
     }
     __syncthreads();
     TM_STAMP(3);
-    // (4) the update of every tile, then the finished pivot rows and columns.  All operand reads
+    // (4) the update of every tile and the finished pivot rows and columns.  All operand reads
     // first (one LDS latency for the lot), then the matrix instructions back to back.
+    // (Tried and not kept, profiles/r03_train_kernel.txt: the finished rows / columns put in BEFORE the matrix
+    // instructions by waves 4..7 -- legal, pivot rows have a zero A operand and pivot columns a zero B operand -- and a
+    // bare s_barrier between the operand reads and the matrix instructions.  While a 64-cycle fp64 matrix
+    // instruction of the other wave holds the SIMD's pipe a wave's vector instructions get in one per 64 cycles, so
+    // whatever is moved under the other wave's matrix phase takes as long as that phase.)
+    auto replace_pivots = [&]() __attribute__((always_inline)) {
+      static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) { replace_tile(tc, hc, q, wv, k0); });
+    };
     {
       const int Rw = wv, Rv = tmNB - 1 - wv;
       const double aw0 = s_C[lrow + 16 * Rw], aw1 = s_C[lrow + 4 * tmLd + 16 * Rw];
@@ -251,6 +321,7 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
         bq[t][0] = s_W[lrow + 16 * C];
         bq[t][1] = s_W[lrow + 4 * tmLd + 16 * C];
       });
+      TM_FINE(4);
       // every tile, also those wholly in the identity padding (their operands are zero): no branch
       // between the tiles, so the 34 matrix instructions of a wave issue back to back
       static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
@@ -263,31 +334,42 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
         tl[t][0] = acc[0]; tl[t][1] = acc[1]; tl[t][2] = acc[2]; tl[t][3] = acc[3];
       });
     }
-    static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value;
-      const int R = t <= wv ? wv : tmNB - 1 - wv, C = t <= wv ? t : t - wv - 1;
-      if (rowmask & (1u << t)) {                // pivot rows of this tile
-        tl[t][2 * h] = s_F[lrow + 16 * C];
-        tl[t][2 * h + 1] = s_F[lrow + 4 * tmLd + 16 * C];
-      }
-      if (colmask & (1u << t)) {                // pivot columns: the signed transpose of the rows
-        if ((ml >> 3) == h) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int il = g + 4 * r, i = 16 * R + il;
-            const bool pivot_row = (R == Ib) && ((il >> 3) == h);
-            if (!pivot_row) {
-              const double rv = s_F[(ml & 7) * tmLd + i];
-              tl[t][r] = (i < k0) ? rv : -rv;
-            }
-          }
+#if GP_TRAIN_STAMPS == 2
+    asm volatile("" :: "v"(tl[tmTiles - 1][0]));     // (the last matrix instruction's result has arrived)
+#endif
+    TM_FINE(5);
+#if GP_TRAIN_MERGED_SWEEP
+    {
+      // (5) and the NEXT pass's (1) in one sweep over the tiles: the tiles either touches are nearly the same ones
+      // (always, when the next pivots are the other half of the same 16-block), a wave has one to three of them
+      // unless it owns the block row, and a tile's tests cost more than its work -- so one test per tile decides
+      // whether any of the four questions is asked.
+      PassGeo qn = geo_of(k0 + tmB, wv);
+      if (k0 + tmB >= N) qn.rowmask = qn.belowmask = 0u;
+      const unsigned any = q.rowmask | q.colmask | qn.rowmask | qn.belowmask;
+      static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) {
+        if (any & (1u << decltype(tc)::value)) {
+          replace_tile(tc, hc, q, wv, k0);
+          stage_tile(tc, HN{}, qn, wv);
         }
-      }
-    });
+      });
+    }
+#else
+    replace_pivots();
+#endif
+    TM_FINE(6);
     // no barrier here: the next pass's step (1) writes s_R only, which nobody reads any more, and
     // its barrier separates this pass's readers of s_W / s_C / s_F from the next pass's writers
-    TM_STAMP(4);
+    TM_COARSE(4);
   };
+#if GP_TRAIN_MERGED_SWEEP
+  {
+    int wv = w;
+    asm volatile("" : "+s"(wv));
+    const PassGeo q0 = geo_of(0, wv);
+    static_for<tmTiles>([&](auto tc) __attribute__((always_inline)) { stage_tile(tc, std::integral_constant<int, 0>{}, q0, wv); });
+  }
+#endif
   for (int kb = 0; kb < N; kb += 2 * tmB) {
     pass(kb, std::integral_constant<int, 0>{});
     if (kb + tmB < N) pass(kb + tmB, std::integral_constant<int, 1>{});
@@ -372,7 +454,7 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
     p.invQt[(long long)e * N + i] = s_a[i];
   }
 
-  TM_STAMP(5);
+  TM_COARSE(5);
   // ---- gradient ------------------------------------------------------------------------------------
   // With c_ij = (invQt_i invQt_j - invQ_ij) Z_ij (gp_train_kernel.hpp, gradient_sums):
   //   dcost/dtheta_d = e_d / 4 sum_ij c_ij (x_id - x_jd)^2,  dcost/dtheta_D = -1/2 sum_ij c_ij,
@@ -435,8 +517,9 @@ __global__ __launch_bounds__(tmThreads, 2) void likelihood_mfma_kernel(TrainArgs
     g_out[D + 1] = 0.5 * s_W[3] * noise - 0.5 * s_W[4] * noise;
   }
 #if GP_TRAIN_STAMPS
-  TM_STAMP(6);
-  if (tid == 0 && e == 0 && p.dbg)
+  TM_COARSE(6);
+  TM_FINE(7);
+  if (tid == 64 * GP_TRAIN_STAMP_WAVE && e == 0 && p.dbg)
     for (int k_ = 0; k_ < 8; ++k_) p.dbg[k_] = seg_sum[k_];
 #endif
 }

@@ -2,6 +2,8 @@
 
     python -m gp_emulator_amd.build --define GP_TRAIN_STAMPS=1 --lib gp_emulator_amd/libgp_predict_hip_tstamps.so
     GP_PREDICT_LIB=gp_emulator_amd/libgp_predict_hip_tstamps.so python tools/train_stamps.py
+(--define GP_TRAIN_STAMPS=2 [--define GP_TRAIN_STAMP_WAVE=4] --only train and GP_TRAIN_STAMPS_FINE=1: the anatomy of a
+pass as wave 0 / wave 4 sees it)
 
 Wave 0 of workgroup 0 of likelihood_mfma_kernel sums s_memtime differences per segment
 (gp_train_mfma_kernel.hpp, TM_STAMP).  Shares only; never a timing of the real kernel."""
@@ -24,9 +26,13 @@ for _ in range(3):
 seg = ctx.to_host(d_dbg, (8,), np.uint64).astype(np.float64)
 names = ["set-up + Q build", "pivot rows -> LDS (+barrier)", "(unused)",
          "panel steps, waves 0-3 (+barrier)", "tile updates (+barrier)", "write-out + invQt", "gradient + sums"]
-tot = seg[:7].sum()
+if os.environ.get("GP_TRAIN_STAMPS_FINE"):    # a --define GP_TRAIN_STAMPS=2 [--define GP_TRAIN_STAMP_WAVE=w] build: a pass's anatomy
+    names = ["set-up + Q build", "pivot rows -> LDS", "barrier behind them", "panel steps (+barrier)",
+             "update: operand reads", "update: matrix instructions", "update: pivot rows / columns replaced",
+             "behind the passes"]
+tot = seg[:len(names)].sum()
 passes = (N + 7) // 8
 print("N=%d D=%d sets=%d: %.0f cycles per evaluation (wave 0 of workgroup 0), %d passes" % (N, D, E, tot, passes))
 for n, v in zip(names, seg):
-    per = "  (%.0f per pass)" % (v / passes) if 1 <= names.index(n) <= 4 else ""
+    per = "  (%.0f per pass)" % (v / passes) if 1 <= names.index(n) <= (6 if len(names) == 8 else 4) else ""
     print("  %-34s %9.0f  %5.1f %%%s" % (n, v, 100 * v / tot, per))
