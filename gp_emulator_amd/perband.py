@@ -166,22 +166,57 @@ class _GatheredObjective(object):
             self._run(batch, -1)
 
 
-def _lockstep_driver():
+_driver_probe = []          # [setulb or None] once probed in this process
+
+
+def _probe_setulb(setulb):
+    """True when ``setulb`` behaves like the routine _Population is written for: called with that
+    argument list on f(x) = (x0 - 1)^2 + (x1 + 2)^2 it asks for f, g with task 3, reports new
+    iterations with task 1 and stops at the minimum within a few evaluations.  A private entry
+    point has no compatibility promise: a scipy that renames an argument, changes a work-array size
+    or the task codes fails here (an exception or a wrong answer), never inside a training run."""
+    pop = _Population(setulb, [(0, 0)], np.array([[3.0, 4.0]]))
+    results = None
+    for _ in range(60):
+        th, es, finished = pop.advance(results)
+        if finished:
+            e, k, cost, theta = finished[0]
+            return bool(np.isfinite(cost) and cost < 1e-12 and np.allclose(theta, [1.0, -2.0], atol=1e-6))
+        if th.shape != (1, 2):
+            return False
+        d = th - np.array([1.0, -2.0])
+        results = (np.sum(d * d, axis=1), 2.0 * d)
+    return False
+
+
+def _lockstep_driver(warn=True):
     """scipy's reverse-communication L-BFGS-B entry point (``scipy.optimize._lbfgsb.setulb``, the
-    routine ``fmin_l_bfgs_b`` itself loops over), or None when this scipy does not have the
-    signature written for here (1.15: C translation, integer task codes)."""
+    routine ``fmin_l_bfgs_b`` itself loops over), or None -- with a warning, once -- when this scipy
+    does not have it in the form written for here (1.15: C translation, integer task codes).  The
+    binding is private, so it is PROBED, not trusted: version, then a run on a two-variable
+    quadratic (``_probe_setulb``).  ``learn_bands(method="auto")`` then uses the threaded driver
+    (one public ``fmin_l_bfgs_b`` per start, objective calls coalesced into batched launches)."""
+    if _driver_probe:
+        return _driver_probe[0]
+    found, why = None, ""
     try:
-        import inspect
         import scipy
-        from scipy.optimize import _lbfgsb, _lbfgsb_py
+        from scipy.optimize import _lbfgsb
         major, minor = (int(v) for v in scipy.__version__.split(".")[:2])
         if (major, minor) < (1, 15):
-            return None
-        if "ln_task" not in inspect.getsource(_lbfgsb_py._minimize_lbfgsb):
-            return None
-        return _lbfgsb.setulb
-    except Exception:
-        return None
+            why = "scipy %s predates the routine's C translation (1.15)" % scipy.__version__
+        elif not _probe_setulb(_lbfgsb.setulb):
+            why = "scipy %s: the routine did not minimise the probe problem with the 1.15 argument list" % scipy.__version__
+        else:
+            found = _lbfgsb.setulb
+    except Exception as exc:
+        why = "%s: %s" % (type(exc).__name__, exc)
+    _driver_probe.append(found)
+    if found is None and warn:
+        import warnings
+        warnings.warn("gp_emulator_amd.perband: scipy.optimize._lbfgsb.setulb is not usable (%s); training falls back "
+                      "to the threaded L-BFGS-B driver (same results, more launches)" % why, RuntimeWarning, stacklevel=2)
+    return found
 
 
 class _Instance(object):

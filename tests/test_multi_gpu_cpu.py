@@ -232,6 +232,37 @@ def test_learn_bands_edge_cases():
         perband.learn_bands(gps, starts=starts, method="bogus", batch_fn=_numpy_objective(X, calls))
 
 
+def test_private_scipy_routine_is_probed_and_falls_back_with_a_warning(monkeypatch):
+    """scipy.optimize._lbfgsb.setulb is private: a scipy whose routine takes other arguments (or answers with other
+    task codes) is found out by the probe run, learn_bands(method="auto") warns once and trains with the threaded
+    driver to the same optimum, method="lockstep" refuses."""
+    from gp_emulator_amd import GaussianProcess, perband
+    from scipy.optimize import _lbfgsb
+    real = perband._lockstep_driver(warn=False)
+    if real is not None:
+        assert perband._probe_setulb(real)
+    assert not perband._probe_setulb(lambda *a: None)                 # a routine that does nothing
+
+    def other_signature(m, x, low, up, nbd, f, g, factr, pgtol, wa, iwa, task, iprint, lsave, isave, dsave, maxls):
+        raise AssertionError("not called with 17 arguments")
+    del perband._driver_probe[:]
+    try:
+        with monkeypatch.context() as mp:                             # (scipy's own fmin_l_bfgs_b calls it too: patched
+            mp.setattr(_lbfgsb, "setulb", other_signature)            # for the probe only)
+            with pytest.warns(RuntimeWarning, match="falls back to the threaded"):
+                assert perband._lockstep_driver() is None
+        X, bands = _bands_problem(n_bands=2)
+        gps = [GaussianProcess(X, t) for t in bands]
+        np.random.seed(3)
+        costs, thetas, stats = perband.learn_bands(gps, n_tries=1, concurrency=2, method="auto",
+                                                   batch_fn=_numpy_objective(X, []))
+        assert stats["method"] == "threads" and np.all(np.isfinite(costs))
+        with pytest.raises(RuntimeError):
+            perband.learn_bands(gps, n_tries=1, method="lockstep", batch_fn=_numpy_objective(X, []))
+    finally:
+        del perband._driver_probe[:]                                  # the next test probes the real routine again
+
+
 def test_learn_bands_lockstep_equals_threads_bit_for_bit():
     """Both drivers feed the same numbers to the same L-BFGS-B routine: identical thetas, and the
     same number of objective evaluations (repeated requests at an unchanged point are served
