@@ -26,6 +26,11 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, unsigned long long*
   for (int i = 0; i < 8; ++i) xp[i] = f32x2{seed + i, seed - i};
   float x16[16];
   for (int i = 0; i < 16; ++i) x16[i] = seed + 2 * i;
+  __shared__ float s_frag[128 * 64];
+  for (int i = threadIdx.x; i < 128 * 64; i += THREADS) s_frag[i] = seed * 1e-3f * (i & 63);
+  __syncthreads();
+  const unsigned lds_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(s_frag))) + (threadIdx.x & 63) * 4;
+  float ring[4] = {0.f, 0.f, 0.f, 0.f};
   const int wave = threadIdx.x >> 6;
   const bool matrix_role = wave < 4;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -92,6 +97,23 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, unsigned long long*
     } else if constexpr (MODE == 14) {    // 40 v_fma_f32 on 16 independent chains
 #pragma unroll
       for (int k = 0; k < 40; ++k) FMA(x16[k & 15]);
+    } else if constexpr (MODE == 20 || MODE == 21 || MODE == 22) {
+      // the predict kernel's phase B in miniature: 40 matrix instructions on ONE accumulator, every A operand read from
+      // LDS (a ring of 4 reads in flight, in-order returns), B operands from 8 registers.  21: the same without the LDS
+      // reads (A from registers); 22: with s_setprio 1 around the matrix instructions
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ring[k]) : "v"(lds_addr), "n"(k * 256));
+#pragma unroll
+      for (int k = 0; k < 40; ++k) {
+        if constexpr (MODE != 21)
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ring[(k + 3) & 3]) : "v"(lds_addr), "n"(((k + 3) % 128) * 256));
+        if constexpr (MODE != 21) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        if constexpr (MODE == 22) asm volatile("s_setprio 1");
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(MODE == 21 ? x[k & 7] : ring[k & 3]), "v"(x[k & 7]));
+        if constexpr (MODE == 22) asm volatile("s_setprio 0");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else if constexpr (MODE == 9) {     // roles by wave: waves 0..3 ten mfma, the others 20 dependent v_fma_f64 (the mean's double sum)
       if (matrix_role) {
 #pragma unroll
@@ -106,6 +128,7 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, unsigned long long*
   float s = (float)xd;
   for (int i = 0; i < 8; ++i) s += x[i] + xp[i][0] + xp[i][1];
   for (int i = 0; i < 16; ++i) s += x16[i];
+  s += ring[0] + ring[1] + ring[2] + ring[3];
   for (int i = 0; i < 10; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) atomicAdd(cyc + (matrix_role ? 0 : 1), t1 - t0);
@@ -144,6 +167,9 @@ int main() {
   ALLW(11, "40-step dependent v_pk_fma_f32 chain")
   ALLW(12, "40 v_pk_fma_f32, one operand broadcast by op_sel_hi")
   ALLW(13, "40 v_pk_add_f32 on 8 independent chains")
+  ALLW(20, "phase B in miniature: 40 mfma, A operands from LDS (ring of 4)")
+  ALLW(21, "the same, A operands from registers")
+  ALLW(22, "the same as the first, s_setprio 1 around each mfma")
   if (run<6, 512>("roles: waves 0-3 ten mfma | waves 4-7 forty independent fmas", d_out, d_cyc)) return 1;
   if (run<6, 768>("roles: waves 0-3 ten mfma | waves 4-11 forty independent fmas", d_out, d_cyc)) return 1;
   if (run<7, 512>("roles: waves 0-3 ten mfma | waves 4-7 a 40-step dependent chain", d_out, d_cyc)) return 1;
